@@ -1,0 +1,165 @@
+"""Deterministic synthetic alignments.
+
+This is the *specification* of the generator, written with numpy uint64
+arithmetic; ``csrc/pfa_synth.hip`` implements the identical integer recipe on
+the device (``pfa_synth_fill_dev``) and on the host (``pfa_synth_fill_host``)
+so that bench-sized batches (BASELINE config 5: 50 GB of bases) never have to
+exist as files.  Everything is integer arithmetic on splitmix64 hashes of
+``(seed, alignment index, site)``; the only floating-point step is the
+threshold table built once per ``(N, theta)`` in :func:`make_params`, which is
+computed here and handed to the native code as integers.
+
+Model: ancestral base uniform over ACGT (coding mode: ancestral codon uniform
+over the 61 sense codons); a site segregates with probability theta * a1(N);
+the derived-allele count k is drawn with P(k) ~ 1/k on 1..N-1 (neutral SFS);
+carriers are the rows r with ((a*r + b) mod N) < k for a per-site random unit
+a and shift b (exactly k carriers); about 1 % of segregating sites carry a
+second derived allele on the first k//2 carriers.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+_U64 = np.uint64
+_GOLDEN = _U64(0x9E3779B97F4A7C15)
+_MIX1 = _U64(0xBF58476D1CE4E5B9)
+_MIX2 = _U64(0x94D049BB133111EB)
+_ALN_MULT = _U64(0xD6E8FEB86659FD93)
+_CODON_SALT = _U64(0xC0D0C0D0C0D0C0D1)
+_INJECT_SALT = _U64(0x1A7EC7ED5EED5EED)
+
+ASCII_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+# sense codons in the 2-bit code A=0,C=1,G=2,T=3 (index = 16*b0 + 4*b1 + b2),
+# derived from the standard code: stops are TAA, TAG, TGA.
+_STOPS = {(3, 0, 0), (3, 0, 2), (3, 2, 0)}
+SENSE_CODE = np.array(
+    [(a, b, c) for a in range(4) for b in range(4) for c in range(4) if (a, b, c) not in _STOPS],
+    dtype=np.uint8,
+)
+assert SENSE_CODE.shape == (61, 3)
+
+
+def splitmix64(x):
+    """splitmix64 finaliser on uint64 scalars/arrays (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = np.asarray(x, dtype=_U64) + _GOLDEN
+        z = (x ^ (x >> _U64(30))) * _MIX1
+        z = (z ^ (z >> _U64(27))) * _MIX2
+        return z ^ (z >> _U64(31))
+
+
+@dataclass(frozen=True)
+class SynthParams:
+    """Integer tables shared by the numpy, host-C++ and device generators."""
+    n_rows: int
+    seg_thresh: int          # of 2**24
+    tri_thresh: int          # of 2**10
+    cdf: np.ndarray          # uint32[n_rows-1], thresholds of 2**24 for k = 1..N-1
+    units: np.ndarray        # uint32[], integers in [1, N) coprime to N (or [1] for N == 1)
+
+
+def make_params(n_rows: int, theta: float, tri_frac: float = 0.01) -> SynthParams:
+    n = int(n_rows)
+    if n < 1:
+        raise ValueError("n_rows must be >= 1")
+    a1 = sum(1.0 / i for i in range(1, n))
+    p_seg = min(max(theta * a1, 0.0), 1.0)
+    seg_thresh = int(p_seg * (1 << 24))
+    acc, cdf = 0.0, []
+    for k in range(1, n):
+        acc += 1.0 / k
+        cdf.append(min(int(acc / a1 * (1 << 24)), 1 << 24))
+    if cdf:
+        cdf[-1] = 1 << 24
+    units = [u for u in range(1, max(n, 2)) if math.gcd(u, n) == 1] or [1]
+    return SynthParams(
+        n_rows=n,
+        seg_thresh=seg_thresh,
+        tri_thresh=int(tri_frac * 1024),
+        cdf=np.asarray(cdf, dtype=np.uint32),
+        units=np.asarray(units, dtype=np.uint32),
+    )
+
+
+def alignment_key(seed: int, aln_index: int) -> np.uint64:
+    with np.errstate(over="ignore"):
+        return splitmix64(_U64(seed) ^ (_U64(aln_index) * _ALN_MULT))
+
+
+def synth_alignment(seed: int, aln_index: int, n_sites: int, params: SynthParams,
+                    coding: bool = False) -> np.ndarray:
+    """uint8 matrix [N, L] of ASCII bases for alignment `aln_index` of stream `seed`."""
+    n, L = params.n_rows, int(n_sites)
+    akey = alignment_key(seed, aln_index)
+    with np.errstate(over="ignore"):
+        site = np.arange(L, dtype=_U64)
+        h1 = splitmix64(akey + site)
+        h2 = splitmix64(h1)
+        if coding:
+            hc = splitmix64((akey ^ _CODON_SALT) + site // _U64(3))
+            anc = SENSE_CODE[(hc % _U64(61)).astype(np.int64), (site % _U64(3)).astype(np.int64)]
+        else:
+            anc = (h1 & _U64(3)).astype(np.uint8)
+        seg = ((h1 >> _U64(2)) & _U64(0xFFFFFF)) < _U64(params.seg_thresh)
+        uk = ((h1 >> _U64(26)) & _U64(0xFFFFFF)).astype(np.uint32)
+        d1 = (((h1 >> _U64(50)) & _U64(0xFF)) % _U64(3)).astype(np.uint8)
+        unit = params.units[((h2 & _U64(0xFFFF)) % _U64(len(params.units))).astype(np.int64)].astype(_U64)
+        shift = ((h2 >> _U64(16)) & _U64(0xFFFFFF)) % _U64(n)
+        tri = ((h2 >> _U64(40)) & _U64(0x3FF)) < _U64(params.tri_thresh)
+    if n < 2:
+        seg = np.zeros(L, dtype=bool)
+        k = np.zeros(L, dtype=np.uint64)
+    else:
+        k = (1 + np.searchsorted(params.cdf, uk, side="right")).astype(_U64)
+        k = np.minimum(k, _U64(n - 1))
+    rows = np.arange(n, dtype=_U64)[:, None]
+    rank = (unit[None, :] * rows + shift[None, :]) % _U64(n)
+    carrier = seg[None, :] & (rank < k[None, :])
+    second = carrier & (tri & (k >= 2))[None, :] & (rank < (k // _U64(2))[None, :])
+    der1 = (anc + 1 + d1) & 3
+    der2 = (anc + 1 + (d1 + 1) % 3) & 3
+    code = np.where(second, der2[None, :], np.where(carrier, der1[None, :], anc[None, :]))
+    return ASCII_ACGT[code.astype(np.int64)]
+
+
+def inject_symbols(matrix: np.ndarray, seed: int, frac: float, alphabet: bytes) -> np.ndarray:
+    """Overwrite about `frac` of the cells with symbols from `alphabet`
+    (hash-driven, reproducible) — gaps, N, IUPAC codes, lower case."""
+    out = matrix.copy()
+    with np.errstate(over="ignore"):
+        idx = np.arange(out.size, dtype=_U64)
+        h = splitmix64((_U64(seed) ^ _INJECT_SALT) + idx)
+    hit = (h & _U64(0xFFFF)) < _U64(int(frac * 65536))
+    sym = np.frombuffer(alphabet, dtype=np.uint8)[((h >> _U64(16)) % _U64(len(alphabet))).astype(np.int64)]
+    flat = out.reshape(-1)
+    flat[hit] = sym[hit]
+    return out
+
+
+def headers_for(n_rows: int, pops: int = 0):
+    """``indiv{i}`` like the reference's examples, or ``pop{1+i%pops}_ind{i}``."""
+    if pops:
+        return [f"pop{1 + i % pops}_ind{i + 1}" for i in range(n_rows)]
+    return [f"indiv{i + 1}" for i in range(n_rows)]
+
+
+def to_dict(headers, matrix: np.ndarray):
+    """dict header -> sequence string, the reference's in-memory alignment."""
+    return {h: bytes(row).decode("ascii") for h, row in zip(headers, matrix)}
+
+
+def to_fasta_text(headers, matrix: np.ndarray, wrap: int = 0, newline: str = "\n") -> str:
+    parts = []
+    for h, row in zip(headers, matrix):
+        seq = bytes(row).decode("ascii")
+        parts.append(">" + h + newline)
+        if wrap:
+            for i in range(0, len(seq), wrap):
+                parts.append(seq[i:i + wrap] + newline)
+        else:
+            parts.append(seq + newline)
+    return "".join(parts)

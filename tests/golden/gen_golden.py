@@ -1,0 +1,439 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container (it imports /root/reference/PolyFastA.py by
+path); nothing in tests/, bench.py or smoke() needs the reference at run time.
+For every fixture family it (1) builds the input with this repo's own
+deterministic generator (polyfasta_amd/synth.py) or from literal text, (2)
+calls the reference function, (3) asserts that the CPU oracle
+(oracle/polyfasta_oracle.py) agrees, and (4) freezes the reference's outputs.
+
+Fixtures are data only: generator parameters / literal FASTA text and the
+reference's outputs.  The ten example alignments are copied as data files
+(they are the only sample inputs the reference ships; GPL-3, attributed in
+tests/golden/example_theta_0.01/ATTRIBUTION).
+
+Families: G1 examples, G2 synthetic grid, G3 odd symbols and
+FASTA syntax, G4 exhaustive codon-set tables, G5 coding alignments, G6
+populations, G7 command-line transcripts.
+"""
+import contextlib
+import hashlib
+import importlib.util
+import io
+import itertools
+import json
+import os
+import random
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF_DIR = "/root/reference"
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from oracle import polyfasta_oracle as orc  # noqa: E402
+from polyfasta_amd import synth  # noqa: E402
+
+spec = importlib.util.spec_from_file_location("PolyFastA", os.path.join(REF_DIR, "PolyFastA.py"))
+ref = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(ref)
+
+
+def close(a, b, tol=1e-11):
+    if isinstance(a, str) or isinstance(b, str):
+        return a == b
+    return abs(a - b) <= tol * max(abs(a), abs(b), 1e-300) or a == b
+
+
+def sha1_ints(xs):
+    return hashlib.sha1(np.asarray(xs, dtype=np.int64).tobytes()).hexdigest()
+
+
+def int_H(var):
+    n = len(var[0]) if var else 0
+    return sum(n * n - sum(col.count(a) ** 2 for a in set(col)) for col in var)
+
+
+def ref_sfs(var):
+    if not var:
+        return None
+    try:
+        return ref.getsfs(var)
+    except IndexError:
+        return "IndexError"
+
+
+def capture(fn, *args):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        fn(*args)
+    return buf.getvalue()
+
+
+def l1_record(d, seqlen, check_oracle=True):
+    """Reference outputs of the non-coding L1 functions on dict `d`."""
+    pos, var = ref.getvarsites(d, seqlen)
+    rec = {
+        "N": len(d), "L": seqlen, "S": len(var), "H": int_H(var),
+        "sfs": ref_sfs(var), "pos_sha1": sha1_ints(pos), "pos_head": pos[:24],
+        "poly": list(ref.polymorphism(var, seqlen, False)),
+        "poly_jc": list(ref.polymorphism(var, seqlen, True)),
+    }
+    if check_oracle:
+        opos, ovar = orc.getvarsites(d, seqlen)
+        assert (opos, ovar) == (pos, var)
+        summ = orc.integer_summary(d, seqlen)
+        assert summ["S"] == rec["S"] and summ["H"] == rec["H"]
+        if var:
+            assert (summ["sfs"] if summ["sfs"] is not None else "IndexError") == rec["sfs"]
+        for jc, key in ((False, "poly"), (True, "poly_jc")):
+            got = orc.polymorphism(ovar, seqlen, jc)
+            assert all(close(x, y) for x, y in zip(got, rec[key])), (got, rec[key])
+    return rec
+
+
+def cds_record(d, seqlen):
+    cs, s, n, nstops, missing = ref.getvarCDSsites(d, seqlen)
+    ocs, os_, on, onstops, omissing = orc.getvarCDSsites(d, seqlen)
+    assert close(cs, ocs, 1e-12) and sorted(s) == sorted(os_) and sorted(n) == sorted(on)
+    assert (nstops, missing) == (onstops, omissing)
+    rows = {}
+    for jc in (False, True):
+        row = capture(ref.print_result, d, seqlen, True, "", "a", "x.fa", "NA", True, 0, jc).rstrip("\n")
+        rows["row_jc" if jc else "row"] = row
+        assert_rows_close(orc.result_row(d, seqlen, True, "x.fa", "NA", jc), row)
+    return {"count_syn": cs, "S_pos": sorted(s), "N_pos": sorted(n), "nstops": nstops,
+            "missing": missing, **rows}
+
+
+def assert_rows_close(a, b):
+    fa, fb = a.split(","), b.split(",")
+    assert len(fa) == len(fb), (a, b)
+    for x, y in zip(fa, fb):
+        if x == y:
+            continue
+        assert close(float(x), float(y), 1e-10), (a, b)
+
+
+def gen_case(seed, aln, N, L, theta, coding=False, inject=None, pops=0):
+    params = synth.make_params(N, theta)
+    m = synth.synth_alignment(seed, aln, L, params, coding=coding)
+    if inject:
+        m = synth.inject_symbols(m, inject["seed"], inject["frac"], inject["alphabet"].encode())
+    return synth.to_dict(synth.headers_for(N, pops), m)
+
+
+def dump(name, obj):
+    path = os.path.join(HERE, name)
+    with open(path, "w") as fh:
+        json.dump(obj, fh, indent=None, separators=(",", ":"))
+        fh.write("\n")
+    print(f"wrote {name}: {os.path.getsize(path)} bytes")
+
+
+# ---------------------------------------------------------------- G1 examples
+def g1():
+    src = os.path.join(REF_DIR, "example_theta_0.01")
+    dst = os.path.join(HERE, "example_theta_0.01")
+    os.makedirs(dst, exist_ok=True)
+    out = {}
+    for fn in sorted(os.listdir(src)):
+        shutil.copyfile(os.path.join(src, fn), os.path.join(dst, fn))
+        os.chmod(os.path.join(dst, fn), 0o644)
+        d = ref.readfasta(os.path.join(src, fn), False)
+        assert d == orc.readfasta(os.path.join(src, fn))
+        L = len(next(iter(d.values())))
+        rec = l1_record(d, L)
+        rec["cds"] = cds_record(d, L)
+        out[fn] = rec
+    with open(os.path.join(dst, "ATTRIBUTION"), "w") as fh:
+        fh.write("file1.fa .. file10.fa are the example alignments shipped with\n"
+                 "https://github.com/santiagosnchez/PolyFastA (example_theta_0.01/, GPL-3.0),\n"
+                 "copied unmodified as test data.\n")
+    dump("g1_examples.json", out)
+
+
+# ---------------------------------------------------------- G2 synthetic grid
+def g2():
+    cases = []
+    Ns = [2, 3, 4, 5, 7, 20, 50, 63, 64, 65, 100, 200, 255, 256, 300]
+    Ls = [1, 3, 15, 16, 17, 239, 240, 241, 255, 256, 257, 1000, 1023, 1025]
+    idx = 0
+    for N in Ns:
+        for L in Ls:
+            for theta in (0.0, 0.01, 0.1):
+                if theta == 0.0 and L not in (1, 16, 1000):
+                    continue
+                if N > 100 and L in (15, 17, 239, 241, 255, 257, 1023):
+                    continue
+                idx += 1
+                g = {"seed": 1000 + idx, "aln": idx % 7, "N": N, "L": L, "theta": theta}
+                d = gen_case(**g)
+                cases.append({"gen": g, **l1_record(d, L)})
+    for N, L, theta in ((50, 10000, 0.01), (200, 10000, 0.01), (50, 4096, 0.3), (20, 3000, 0.05)):
+        idx += 1
+        g = {"seed": 1000 + idx, "aln": 3, "N": N, "L": L, "theta": theta}
+        d = gen_case(**g)
+        cases.append({"gen": g, **l1_record(d, L)})
+    # odd symbols injected into the matrix (upper-case only: L1 sees readfasta output)
+    for N, L, frac, alphabet in ((20, 1000, 0.01, "-N"), (50, 1500, 0.002, "-N"),
+                                 (7, 600, 0.05, "RYKMSWBDHVN-?"), (64, 700, 0.01, "-NRYU*."),
+                                 (33, 512, 0.3, "-N"), (12, 300, 0.9, "-"), (100, 800, 0.001, "N"),
+                                 (5, 400, 0.2, "@BDEFPQUVW")):
+        idx += 1
+        g = {"seed": 1000 + idx, "aln": 1, "N": N, "L": L, "theta": 0.02,
+             "inject": {"seed": 77 + idx, "frac": frac, "alphabet": alphabet}}
+        d = gen_case(**g)
+        cases.append({"gen": g, **l1_record(d, L)})
+    dump("g2_synthetic.json", cases)
+
+
+# ------------------------------------------------ G3 FASTA syntax / symbols
+G3_TEXTS = {
+    "plain": ">a\nACGT\n>b\nACGA\n>c\nACGA\n",
+    "lower_and_wrapped": ">s1 desc\nacgtac\ngtac\n>s2\nACGTAC\nGTAA\n>s3\nAcGtAc\nGtAn\n",
+    "crlf": ">a\r\nACGT-\r\n>b\r\nACGTN\r\n>c\r\nAC-TN\r\n",
+    "lone_cr": ">a\rACGT\r>b\rACGA\r",
+    "blank_lines": ">a\n\nAC\n\nGT\n>b\nAC\nGA\n\n",
+    "pre_header_text": "junk line\nmore junk\n>a\nACGT\n>b\nTCGT\n",
+    "dup_header": ">a\nAAAA\n>b\nACGT\n>a\nACGA\n",
+    "trailing_ws": ">a  \nAC GT \t\n>b\nAC GA\n>c\nACTGA\n",
+    "no_final_newline": ">a\nACGT\n>b\nACGG",
+    "gaps_iupac": ">a\nACGTRYKM--NN\n>b\nACGTRYKM-ANN\n>c\nACGARYKA-ANC\n>d\nTCGARYKA--NC\n",
+    "one_acgt_allele": ">a\nAN\n>b\nA-\n>c\nAN\n",
+    "unequal": ">a\nACGT\n>b\nACG\n",
+    "empty_header_mid": ">a\nACGT\n>\nACGT\n>b\nACGA\n",
+    "empty_header_last": ">a\nACGT\n>b\nACGA\n>\nACGT\n",
+    "not_fasta": "ACGT\nACGT\n",
+    "empty_file": "",
+    "single_seq": ">only\nACGTACGT\n",
+    "control_ws": ">a\nACGT\x0b\x0c\n>b\nACGA\x1c\x1d\x1e\x1f\n>c\nAC\x0cGT\n>d\nAC\x0cGA\n",
+    "header_only": ">a\n>b\n",
+    "gt_inside": ">a\nAC>GT\n>b\nAC>GA\n",
+}
+
+
+def g3():
+    out = {}
+    for name, text in G3_TEXTS.items():
+        with tempfile.NamedTemporaryFile("w", suffix=".fa", delete=False, newline="") as fh:
+            fh.write(text)
+            path = fh.name
+        msg = io.StringIO()
+        with contextlib.redirect_stdout(msg):
+            d = ref.readfasta(path, False)
+        od = orc.readfasta(path)
+        os.unlink(path)
+        rec = {"text": text}
+        if d == 1:
+            assert od is None
+            rec["records"] = None
+        else:
+            assert od == d
+            rec["records"] = [[h, s] for h, s in d.items()]
+            lens = [len(s) for s in d.values()]
+            rec["same_length"] = all(x == lens[0] for x in lens)
+            if rec["same_length"]:
+                rec.update(l1_record(d, lens[0]))
+                rec["row"] = capture(ref.print_result, d, lens[0], False, "", "a", name, "NA", True, 0, False).rstrip("\n")
+        out[name] = rec
+    dump("g3_fasta_syntax.json", out)
+
+
+# ----------------------------------------------------- G4 codon-set tables
+def _pack(s, n, start):
+    """6-bit code: bits 0-2 synonymous positions, bits 3-5 non-synonymous."""
+    code = 0
+    for p in s:
+        code |= 1 << (p - start)
+    for p in n:
+        code |= 8 << (p - start)
+    return code
+
+
+def g4():
+    sense = list(orc.SENSE_CODONS)
+    allc = sorted(orc.AMINO)
+    out = {"sense": sense, "all": allc}
+    pairs = []
+    for a, b in itertools.combinations(sense, 2):
+        s, n = ref.get_syn_nonsyn_cod_sites([[a, b], 0])
+        s2, n2 = ref.get_syn_nonsyn_cod_sites([[b, a], 0])
+        assert (sorted(s), sorted(n)) == (sorted(s2), sorted(n2))
+        assert orc.get_syn_nonsyn_cod_sites([[a, b], 0]) == (s, n)
+        pairs.append(_pack(s, n, 0))
+    out["pairs"] = pairs                     # itertools.combinations(sense, 2) order
+    triples = []
+    for t in itertools.combinations(sense, 3):
+        s, n = ref.get_syn_nonsyn_cod_sites([list(t), 0])
+        assert orc.get_syn_nonsyn_cod_sites([list(t), 0]) == (s, n)
+        triples.append(_pack(s, n, 0))
+    out["triples"] = bytes(triples).hex()    # itertools.combinations(sense, 3) order
+    rng = random.Random(20261003)
+    sets = []
+    for _ in range(12000):
+        k = rng.randint(2, 10) if rng.random() < 0.9 else rng.randint(11, 40)
+        pool = allc if rng.random() < 0.3 else sense
+        cs = rng.sample(pool, k)
+        s, n = ref.get_syn_nonsyn_cod_sites([list(cs), 0])
+        assert orc.get_syn_nonsyn_cod_sites([list(cs), 0]) == (s, n)
+        sets.append(["".join(cs), _pack(s, n, 0)])
+    out["sets"] = sets
+    out["syn_thirds"] = {c: round(ref.syncodfreq(c) * 3) for c in allc}
+    for c in allc:
+        assert ref.syncodfreq(c) == orc.syncodfreq(c)
+    dump("g4_codon_sets.json", out)
+
+
+# ----------------------------------------------------- G5 coding alignments
+def g5():
+    cases = []
+    specs = [
+        dict(seed=501, aln=0, N=50, L=9000, theta=0.01, coding=True),
+        dict(seed=502, aln=1, N=50, L=9000, theta=0.05, coding=True),
+        dict(seed=503, aln=2, N=20, L=1000, theta=0.02, coding=True),       # L % 3 == 1
+        dict(seed=504, aln=0, N=20, L=1001, theta=0.02, coding=True),       # L % 3 == 2
+        dict(seed=505, aln=0, N=8, L=720, theta=0.2, coding=True),
+        dict(seed=506, aln=0, N=100, L=2400, theta=0.01, coding=True),
+        dict(seed=507, aln=0, N=3, L=240, theta=0.1, coding=True),
+        dict(seed=508, aln=0, N=64, L=480, theta=0.3, coding=True),
+        dict(seed=509, aln=0, N=30, L=1500, theta=0.02, coding=True,
+             inject={"seed": 9, "frac": 0.01, "alphabet": "-N"}),
+        dict(seed=510, aln=0, N=30, L=1500, theta=0.02, coding=True,
+             inject={"seed": 10, "frac": 0.2, "alphabet": "-NRY"}),
+        dict(seed=511, aln=0, N=12, L=600, theta=0.0, coding=True),         # no variation
+        dict(seed=512, aln=0, N=50, L=9000, theta=0.01, coding=False),      # random frame: many stops
+        dict(seed=513, aln=0, N=2, L=300, theta=0.2, coding=True),
+        dict(seed=514, aln=0, N=1, L=300, theta=0.2, coding=True),
+        dict(seed=515, aln=0, N=40, L=2, theta=0.5, coding=False),          # single partial codon
+        dict(seed=516, aln=0, N=40, L=241, theta=0.1, coding=True),
+        dict(seed=517, aln=0, N=40, L=239, theta=0.1, coding=True),
+    ]
+    for g in specs:
+        d = gen_case(**g)
+        rec = {"gen": g, **l1_record(d, g["L"]), "cds": cds_record(d, g["L"])}
+        cases.append(rec)
+    tiny = {"a": "ATGTAAGGG", "b": "ATGTACGGG", "c": "ATGTACGGA"}
+    cases.append({"literal": tiny, **l1_record(tiny, 9), "cds": cds_record(tiny, 9)})
+    dump("g5_cds.json", cases)
+
+
+# ------------------------------------------------------------ G6 populations
+def g6():
+    out = []
+    g = dict(seed=601, aln=0, N=60, L=3000, theta=0.02, pops=2)
+    d = gen_case(**g)
+    # add pop10_* rows so that key "pop1" also matches "pop10_x" (substring semantics)
+    d2 = dict(d)
+    extra = gen_case(seed=602, aln=0, N=6, L=3000, theta=0.02)
+    for i, (h, s) in enumerate(extra.items()):
+        d2[f"pop10_x{i}"] = s
+    for label, dd, keys in (("two_pops", d, ["pop1", "pop2"]),
+                            ("substring", d2, ["pop1", "pop10", "pop2", "pop", "absent"])):
+        rows = {}
+        for key in keys:
+            grp = {h: s for h, s in dd.items() if key in h}
+            assert grp == orc.split_pop(dd, key)
+            if not grp:
+                rows[key] = None
+                continue
+            for cds in (False, True):
+                for jc in (False, True):
+                    row = capture(ref.print_result, grp, 3000, cds, "", "a", "x.fa", key, True, 0, jc).rstrip("\n")
+                    assert_rows_close(orc.result_row(grp, 3000, cds, "x.fa", key, jc), row)
+                    rows[f"{key}|cds={int(cds)}|jc={int(jc)}"] = row
+        out.append({"label": label, "gen": g, "extra_gen": dict(seed=602, aln=0, N=6, L=3000, theta=0.02) if label == "substring" else None,
+                    "rows": rows})
+    dump("g6_pops.json", out)
+
+
+# ------------------------------------------------------- G7 CLI transcripts
+def run_cli(args, stdin_text=None, cwd=None):
+    p = subprocess.run([sys.executable, os.path.join(REF_DIR, "PolyFastA.py")] + args,
+                       input=None if stdin_text is None else stdin_text.encode(),
+                       capture_output=True, cwd=cwd,
+                       env={**os.environ, "PYTHONHASHSEED": "0"})
+    # bytes -> str without newline translation (the progress line uses "\r")
+    p.stdout = p.stdout.decode()
+    p.stderr = p.stderr.decode()
+    return p
+
+
+def g7():
+    ex = os.path.join(HERE, "example_theta_0.01")
+    out = {}
+    tmp = tempfile.mkdtemp()
+    odd = os.path.join(tmp, "odd")
+    os.makedirs(odd)
+    for name in ("unequal", "not_fasta", "plain", "single_seq"):
+        with open(os.path.join(odd, name + ".fa"), "w", newline="") as fh:
+            fh.write(G3_TEXTS[name])
+    novar = os.path.join(tmp, "novar.fa")
+    with open(novar, "w") as fh:
+        fh.write(">a\nATGAAACCC\n>b\nATGAAACCC\n")
+
+    def rel(p):
+        return p.replace(HERE + "/", "{GOLDEN}/").replace(tmp + "/", "{TMP}/")
+
+    runs = {
+        "file1": ["-f", f"{ex}/file1.fa"],
+        "two_files": ["-f", f"{ex}/file2.fa", f"{ex}/file1.fa"],
+        "file1_jc": ["-f", f"{ex}/file1.fa", "--jc"],
+        "file1_cds": ["-f", f"{ex}/file1.fa", "--cds"],
+        "file1_cds_jc": ["-f", f"{ex}/file1.fa", "-c", "--jc"],
+        "file1_silent": ["-f", f"{ex}/file1.fa", "-s"],
+        "odd_dir": ["-d", odd],
+        "odd_dir_cds": ["-d", odd, "--cds"],
+        "novar": ["-f", novar],
+        "novar_cds": ["-f", novar, "--cds"],
+    }
+    for name, args in runs.items():
+        p = run_cli(args)
+        out[name] = {"args": [rel(a) for a in args], "stdout": p.stdout.replace(tmp + "/", "{TMP}/"), "returncode": p.returncode}
+    # --dir on the examples: strip the ATTRIBUTION file by using a clean copy
+    exdir = os.path.join(tmp, "examples")
+    os.makedirs(exdir)
+    for fn in os.listdir(ex):
+        if fn.endswith(".fa"):
+            shutil.copyfile(os.path.join(ex, fn), os.path.join(exdir, fn))
+    for name, extra in (("dir", []), ("dir_jc", ["--jc"]), ("dir_cds", ["--cds"]), ("dir_cds_jc", ["--cds", "--jc"])):
+        p = run_cli(["-d", exdir] + extra)
+        out[name] = {"args": ["-d", "{EXAMPLES}"] + extra, "stdout": p.stdout, "returncode": p.returncode}
+    # --pipe with and without a name
+    text = open(f"{ex}/file3.fa").read()
+    for name, args in (("pipe", ["--pipe"]), ("pipe_named", ["-i", "-n", "regionX"]), ("pipe_cds", ["-i", "-c"])):
+        p = run_cli(args, stdin_text=text)
+        out[name] = {"args": args, "stdin_file": "file3.fa", "stdout": p.stdout, "returncode": p.returncode}
+    # --out: header written with 'w', rows appended; progress text on stdout
+    outcsv = os.path.join(tmp, "res.csv")
+    p = run_cli(["-f", f"{ex}/file1.fa", f"{ex}/file2.fa", "-o", outcsv])
+    out["out_file"] = {"args": ["-f", "{GOLDEN}/example_theta_0.01/file1.fa", "{GOLDEN}/example_theta_0.01/file2.fa", "-o", "{TMP}/res.csv"],
+                       "stdout": p.stdout.replace(outcsv, "{TMP}/res.csv"), "file": open(outcsv).read(), "returncode": p.returncode}
+    p = run_cli(["-f", f"{ex}/file3.fa", "-o", outcsv, "-s"])
+    out["out_file_silent_append"] = {"args": ["-f", "{GOLDEN}/example_theta_0.01/file3.fa", "-o", "{TMP}/res.csv", "-s"],
+                                     "stdout": p.stdout, "file": open(outcsv).read(), "returncode": p.returncode}
+    outcsv2 = os.path.join(tmp, "res2.csv")
+    p = run_cli(["-d", odd, "--cds", "-o", outcsv2])
+    out["out_file_odd_cds"] = {"args": ["-d", "{TMP}/odd", "--cds", "-o", "{TMP}/res2.csv"],
+                               "stdout": p.stdout.replace(tmp + "/", "{TMP}/"), "file": open(outcsv2).read(), "returncode": p.returncode}
+    # argument errors
+    p = run_cli(["-f", f"{ex}/file1.fa", "-d", exdir])
+    out["file_and_dir"] = {"args": ["-f", "x", "-d", "y"], "returncode": p.returncode, "stderr_tail": p.stderr.strip().splitlines()[-1]}
+    p = run_cli(["-f", f"{ex}/file1.fa", "--pipe"], stdin_text=text)
+    out["file_and_pipe"] = {"args": ["-f", "x", "--pipe"], "returncode": p.returncode, "stderr_tail": p.stderr.strip().splitlines()[-1]}
+    out["_odd_texts"] = {n: G3_TEXTS[n] for n in ("unequal", "not_fasta", "plain", "single_seq")}
+    out["_novar_text"] = ">a\nATGAAACCC\n>b\nATGAAACCC\n"
+    shutil.rmtree(tmp)
+    dump("g7_cli.json", out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    for w in which:
+        globals()[w]()
