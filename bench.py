@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — the polymorphism-scan hot path on N GPUs of one node.
+
+A *step* is one pass of the scan kernel over one device-resident batch of
+synthetic alignments (BASELINE.json configs[1] shape: N=50 sequences x L=10 kb,
+theta = 0.01, non-coding; `--batch` of them per GPU, distinct, generated on the
+device by the deterministic generator, so the working set is several times the
+256 MiB Infinity Cache).  Multi-GPU = the reference's `--dir` batch mode:
+independent alignments sharded over ranks (weak scaling: every rank scans its
+own `--batch` alignments per step), no collective on the data path, ONE RCCL
+all-gather of the fixed-size result records at the end, inside the timed region.
+
+Prints one JSON line on rank 0 (contract in the task statement) carrying
+`roofline` (algorithmic bytes = N*L per alignment, kernel time from HIP events
+recorded on the launch stream) and `cpu_baseline` (the C oracle, one core, on a
+bounded sample of the same workload; N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8192, help="alignments per GPU per step")
+    ap.add_argument("--rows", type=int, default=50)
+    ap.add_argument("--sites", type=int, default=10000)
+    ap.add_argument("--theta", type=float, default=0.01)
+    ap.add_argument("--stride-align", type=int, default=16)
+    ap.add_argument("--variant", type=int, default=0, help="0 = LDS-DMA staging, 1 = register staging")
+    ap.add_argument("--coding", action="store_true", help="scan as in-frame CDS (config 4 shape with --sites 9000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, params):
+    """Time the C oracle (scalar, one core) on a bounded sample of the workload."""
+    from oracle import c_oracle
+    from polyfasta_amd import _lib, scan
+    n_mat = 128
+    stride = scan.row_stride_for(args.sites, args.stride_align)
+    sp = _lib.SynthParamsC(seed=2026, first_aln=0, n_aln=n_mat, n_rows=args.rows, n_sites=args.sites,
+                           row_stride=stride, seg_thresh=params.seg_thresh, tri_thresh=params.tri_thresh,
+                           n_units=len(params.units), coding=0)
+    bases = np.zeros(n_mat * args.rows * stride, dtype=np.uint8)
+    _lib.check(_lib.load().pfa_synth_fill_host(_lib.ptr(bases), ctypes.byref(sp),
+                                               _lib.ptr(np.ascontiguousarray(params.cdf)),
+                                               _lib.ptr(np.ascontiguousarray(params.units))))
+    c_oracle.scan_many(bases, 4, args.rows, args.sites, stride)  # warm
+    done, t0 = 0, time.perf_counter()
+    while True:
+        s, h = c_oracle.scan_many(bases, n_mat, args.rows, args.sites, stride)
+        done += n_mat
+        dt = time.perf_counter() - t0
+        if dt >= args.cpu_seconds:
+            break
+    return {"value": done / dt, "unit": "alignments/s", "cores": 1, "kind": "port",
+            "sample": f"{n_mat} distinct synthetic alignments ({args.rows}x{args.sites}, same generator) scanned "
+                      f"repeatedly by oracle/pfa_oracle.c for {dt:.1f} s on 1 of {os.cpu_count()} host cores",
+            "host_cores": os.cpu_count()}, (s, h)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from polyfasta_amd import _lib, scan, synth
+
+    lib = _lib.load()
+    _lib.init(local_rank)
+
+    N, L, B = args.rows, args.sites, args.batch
+    params = synth.make_params(N, args.theta)
+    stride = scan.row_stride_for(L, args.stride_align)
+    nbytes = B * N * stride
+    dev = scan.DeviceBuffer(nbytes)
+    sp = _lib.SynthParamsC(seed=2026, first_aln=rank * B, n_aln=B, n_rows=N, n_sites=L, row_stride=stride,
+                           seg_thresh=params.seg_thresh, tri_thresh=params.tri_thresh, n_units=len(params.units),
+                           coding=int(args.coding))
+    _lib.check(lib.pfa_synth_fill_dev(dev.ptr, ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(params.cdf)),
+                                      _lib.ptr(np.ascontiguousarray(params.units))))
+    descs = np.zeros(B, dtype=_lib.DESC_DTYPE)
+    descs["base_off"] = np.arange(B, dtype=np.uint64) * np.uint64(N * stride)
+    descs["n_rows"], descs["n_sites"], descs["row_stride"], descs["mat_rows"] = N, L, stride, N
+    descs["row_idx_off"] = _lib.PFA_NO_ROW_IDX
+    descs["flags"] = _lib.PFA_FLAG_CDS if args.coding else 0
+    table = scan.finalize_layout(descs, None, nbytes)
+    plan = scan.Plan(table)
+
+    def sync_all():
+        _lib.check(lib.pfa_sync())
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plan.run(dev, variant=args.variant)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.run(dev, variant=args.variant)
+    _lib.check(lib.pfa_sync())
+    out = plan.fetch()                       # D2H of the integer records (part of the job)
+    gathered = None
+    if dist is not None:                      # the only collective: result records to every rank
+        import torch
+        local = torch.from_numpy(out.results.view(np.uint8).reshape(-1).copy()).cuda()
+        allr = torch.empty(world * local.numel(), dtype=torch.uint8, device="cuda")
+        dist.all_gather_into_tensor(allr, local)
+        torch.cuda.synchronize()
+        gathered = allr.cpu().numpy().view(_lib.RESULT_DTYPE)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    kms = plan.kernel_ms(args.steps)
+    k_avg_ms = float(kms.mean()) if len(kms) else float("nan")
+    alg_bytes = float(B) * N * L
+    achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+
+    if rank == 0:
+        res = out.results
+        total_aln = world * B * args.steps
+        line = {
+            "metric": "alignments/sec", "value": total_aln / dt, "unit": "alignments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "site_columns_per_sec": total_aln * L / dt,
+            "config": {"workload": f"BASELINE configs[1] shape as a device-resident batch: {B} distinct alignments "
+                                   f"per GPU per step, N={N} x L={L}, theta={args.theta}, "
+                                   f"{'coding (--cds)' if args.coding else 'non-coding'}",
+                       "rows": N, "sites": L, "batch_per_gpu": B, "row_stride": stride,
+                       "parallelism": f"independent alignments sharded over {world} rank(s); one RCCL all-gather of result records"
+                                      if world > 1 else "single GPU",
+                       "kernel_variant": "lds_dma" if args.variant == 0 else "register_staged",
+                       "tiles_per_chunk": plan.tiles_per_chunk, "lds_bytes_per_wave": plan.lds_bytes},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pfa::scan_kernel", "kernel_ms_avg": k_avg_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac_of_measured_copy_6290": achieved / 6290.0},
+            "check": {"mean_seg_sites": float(res["seg_sites"].mean()),
+                      "sum_H": int(res["H"].sum()),
+                      "gathered_records": None if gathered is None else int(len(gathered))},
+        }
+        if world == 1 and not args.no_cpu_baseline and not args.coding:
+            cb, (s_cpu, h_cpu) = cpu_baseline(args, params)
+            line["cpu_baseline"] = cb
+            # the CPU sample is the first 128 alignments of rank 0's batch: integers must agree
+            line["check"]["cpu_sample_matches_gpu"] = bool(
+                (res["seg_sites"][:len(s_cpu)] == s_cpu).all() and (res["H"][:len(h_cpu)] == h_cpu).all())
+        print(json.dumps(line), flush=True)
+
+    plan.close()
+    dev.free()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

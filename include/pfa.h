@@ -1,0 +1,223 @@
+/* pfa.h — C ABI of libpfa_hip.so: the MI355X (gfx950) polymorphism-scan path of
+ * PolyFastA, behind plain pointers and sizes (no C++ or torch types).
+ *
+ * What this boundary replaces.  The reference (PolyFastA.py, pure Python) has no
+ * FFI; its only seam is the Python call boundary around the statistics kernel,
+ * used from one place, print_result.no_header (PolyFastA.py:148-198):
+ *
+ *     getvarsites(d, seqlen)      -> (pos, var)                PolyFastA.py:252-261
+ *     getsfs(var)                 -> folded SFS                PolyFastA.py:274-282
+ *     getvarCDSsites(d, seqlen)   -> (syn sites, S, N, nstops, missing)   :284-315
+ *     get_syn_nonsyn_cod_sites()  -> codon-set classifier      PolyFastA.py:319-434
+ *     polymorphism(var, len, jc)  -> (S, pi, theta_w, D)       PolyFastA.py:502-520
+ *
+ * A maintainer binds this library with ctypes (INTEGRATION.md shows the stub)
+ * and replaces those calls: the device returns exact INTEGER summaries per scan
+ * unit (an alignment, or a population's row subset of one); every
+ * floating-point step (pi, theta_w, Tajima's D, Jukes-Cantor, "NA" rules, CSV
+ * text) stays in the host language, where its rounding mirrors the reference.
+ *
+ * Conventions: every function returns 0 on success or a negative PFA_ERR_*
+ * code and records a message retrievable with pfa_last_error() (thread-local).
+ * No exceptions or aborts cross the ABI.  One process drives one GPU
+ * (pfa_init(device)); calls are not re-entrant across threads.  The caller owns
+ * every host buffer; the library keeps no host pointer after a call returns.
+ * There is NO CPU fallback: without a gfx950 device pfa_init() fails.
+ */
+#ifndef PFA_H
+#define PFA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFA_ABI_VERSION 1
+
+/* error codes */
+#define PFA_OK 0
+#define PFA_ERR_NO_DEVICE (-1)  /* no HIP device / wrong architecture        */
+#define PFA_ERR_NOT_INIT (-2)   /* pfa_init() has not succeeded               */
+#define PFA_ERR_ARG (-3)        /* bad argument or descriptor                 */
+#define PFA_ERR_HIP (-4)        /* a HIP runtime call failed                  */
+#define PFA_ERR_TOO_MANY_ROWS (-5) /* n_rows above PFA_MAX_ROWS               */
+#define PFA_ERR_NOMEM (-6)
+#define PFA_ERR_FORMAT (-7)     /* FASTA packer: not FASTA / unsupported byte */
+#define PFA_ERR_IO (-8)
+
+/* Rows of one scan unit must fit one LDS column tile. */
+#define PFA_MAX_ROWS 2048u
+
+#define PFA_NO_ROW_IDX 0xFFFFFFFFu
+
+/* pfa_desc.flags */
+#define PFA_FLAG_CDS 1u /* in-frame coding sequence: also produce the syn/nonsyn split */
+
+/* pfa_plan_create() `want` bits: optional per-site outputs */
+#define PFA_WANT_VAR_BITMAP 1u /* variable-site bitmap  -> `pos` of getvarsites        */
+#define PFA_WANT_SN_BITMAP 2u  /* S / N position bitmaps -> lists of getvarCDSsites    */
+
+/* Column-tile widths (sites per wavefront tile) for plans whose largest unit has
+ * at most 600 rows; above that the tile narrows to 64 / 48 sites so that N rows
+ * still fit LDS.  Query with pfa_tile_sites().  Bitmaps are laid out per tile. */
+#define PFA_TILE_SITES 256u     /* non-coding units                                    */
+#define PFA_TILE_SITES_CDS 240u /* coding units: 80 whole codons, 16-byte aligned start */
+
+/* One scan unit = one alignment, or one population's row subset of an
+ * alignment (PolyFastA.py:122-134).  `bases` holds row-major matrices, ONE
+ * UPPER-CASE ASCII BYTE PER BASE exactly as readfasta (PolyFastA.py:227-250)
+ * would produce them; every distinct byte value is an allele (PolyFastA.py:258). */
+typedef struct pfa_desc {
+  uint64_t base_off;    /* byte offset of (row 0, site 0) in `bases`; multiple of 16        */
+  uint32_t n_rows;      /* N: sequences in this unit (<= PFA_MAX_ROWS)                       */
+  uint32_t n_sites;     /* L: alignment length                                               */
+  uint32_t row_stride;  /* bytes between matrix rows; multiple of 16 and >= round_up(L, 16)  */
+  uint32_t row_idx_off; /* offset into row_idx[] of the unit's n_rows matrix row numbers,
+                           or PFA_NO_ROW_IDX for rows 0..n_rows-1                            */
+  uint32_t flags;       /* PFA_FLAG_*                                                        */
+  uint32_t sfs_off;     /* offset (in uint32) of this unit's floor(N/2) SFS bins in `sfs`    */
+  uint32_t tile_off;    /* index of this unit's first tile in the bitmap outputs             */
+  uint32_t mat_rows;    /* rows of the underlying matrix (bounds check of row_idx entries)   */
+} pfa_desc;
+
+/* Integer summary of one scan unit.  theta_pi total =
+ * H / (N (N-1)); theta_w total = S / a1; see polyfasta_amd/stats.py. */
+typedef struct pfa_result {
+  uint64_t H;            /* sum over variable sites of (N^2 - sum_j c_j^2)   (PolyFastA.py:485-492) */
+  uint64_t H_S;          /* same, over sites called synonymous               (PolyFastA.py:169,172) */
+  uint64_t H_N;          /* same, over sites called non-synonymous           (PolyFastA.py:170,173) */
+  uint32_t seg_sites;    /* S = len(var)                                     (PolyFastA.py:258)     */
+  uint32_t sfs_bad;      /* variable columns with < 2 A/C/G/T alleles: getsfs raises IndexError there */
+  uint32_t seg_S;        /* synonymous segregating sites                                            */
+  uint32_t seg_N;        /* non-synonymous segregating sites                                        */
+  uint32_t nstops;       /* codon columns containing a stop codon            (PolyFastA.py:293)     */
+  uint32_t missing_cols; /* codon columns without any clean codon; missingcodpos = 3 x this (:305)  */
+  uint32_t status;       /* 0                                                                       */
+  uint32_t reserved;
+} pfa_result;
+
+/* syn_num layout: PFA_SYN_BINS uint32 per unit; bin k (1..64) holds the sum,
+ * over codon columns with exactly k distinct clean codons, of the number of
+ * synonymous single-nucleotide neighbours of those codons.  The synonymous
+ * site count of PolyFastA.py:307 is sum_k syn_num[k] / (3 k).  Bin 0 unused. */
+#define PFA_SYN_BINS 65u
+
+typedef struct pfa_plan pfa_plan;
+
+/* tile geometry of a plan whose largest unit has `max_rows` rows: sites per
+ * tile (coding / non-coding units), 64-bit words per tile of the variable-site
+ * bitmap and of each S / N bitmap.  tile_off of unit i = sum over earlier units
+ * of ceil(n_sites / pfa_tile_sites(max_rows, unit is coding)). */
+uint32_t pfa_tile_sites(uint32_t max_rows, uint32_t cds);
+uint32_t pfa_var_words_per_tile(uint32_t max_rows);
+uint32_t pfa_sn_words_per_tile(uint32_t max_rows);
+
+/* ---- context -------------------------------------------------------------- */
+int pfa_abi_version(void);
+int pfa_device_count(void);
+int pfa_init(int device);
+void pfa_shutdown(void);
+const char* pfa_last_error(void);
+int pfa_sync(void);
+
+/* ---- device memory (plain device pointers) -------------------------------- */
+int pfa_dev_alloc(size_t bytes, void** out);
+int pfa_dev_free(void* p);
+int pfa_upload(void* dst_dev, const void* src_host, size_t bytes);
+int pfa_download(void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- scan plans ------------------------------------------------------------
+ * A plan validates and uploads a descriptor table and owns the device-side
+ * output buffers; it can be run any number of times on device-resident bases. */
+int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc,
+                    const uint32_t* row_idx, size_t n_row_idx,
+                    uint64_t n_bases_bytes, uint32_t want, pfa_plan** out);
+/* launch on the context stream; asynchronous; returns after enqueue.
+ * `variant`: 0 = default kernel, 1 = register-staged tile (A/B measurements) */
+int pfa_plan_run(pfa_plan* plan, const uint8_t* d_bases, int variant);
+/* elapsed milliseconds (HIP events on the launch stream) of the scan kernel of
+ * the most recent `n` runs, oldest first; returns the count written or <0 */
+int pfa_plan_kernel_ms(pfa_plan* plan, float* ms_out, int n);
+/* synchronise and copy outputs to host; any pointer may be NULL.
+ * sizes: results[n_desc], sfs[sfs_words], syn_num[n_desc*PFA_SYN_BINS],
+ *        var_bitmap[n_tiles * pfa_var_words_per_tile()], syn/non_bitmap[n_tiles *
+ *        pfa_sn_words_per_tile()] uint64 (tile-interleaved, below) */
+int pfa_plan_fetch(pfa_plan* plan, pfa_result* results, uint32_t* sfs, uint32_t* syn_num,
+                   uint64_t* var_bitmap, uint64_t* syn_bitmap, uint64_t* non_bitmap);
+/* device pointer of the result records (n_desc x pfa_result), e.g. to hand to
+ * an RCCL gather without a host round trip */
+int pfa_plan_results_dev(pfa_plan* plan, void** d_results, size_t* bytes);
+uint32_t pfa_plan_n_tiles(const pfa_plan* plan);
+uint32_t pfa_plan_tiles_per_chunk(const pfa_plan* plan); /* launch geometry, for reports */
+uint32_t pfa_plan_lds_bytes(const pfa_plan* plan);
+uint64_t pfa_plan_sfs_words(const pfa_plan* plan);
+void pfa_plan_destroy(pfa_plan* plan);
+
+/* one-shot: host bases in, host summaries out (H2D + scan + D2H) */
+int pfa_scan_batch(const uint8_t* bases, uint64_t n_bases_bytes,
+                   const pfa_desc* descs, uint32_t n_desc,
+                   const uint32_t* row_idx, size_t n_row_idx,
+                   pfa_result* results, uint32_t* sfs, uint32_t* syn_num,
+                   uint64_t* var_bitmap, uint64_t* syn_bitmap, uint64_t* non_bitmap);
+
+/* Bitmap layout ("tile-interleaved", the order the wavefront ballots produce).
+ * var_bitmap: W = pfa_var_words_per_tile() words per tile (4, or 1 for narrow
+ * tiles); bit l of word b of tile t <-> site t*TILE + W*l + b.  syn/non bitmaps:
+ * 3*G words per tile (coding units only; G = 2 for 240-site tiles, 1 for 48);
+ * bit l of word 3*g + p <-> site t*TILE + 3*(64*g + l) + p.
+ * pfa_bitmap_positions() expands one unit's words to ascending positions;
+ * returns the count, or <0 if `cap` is too small. */
+int64_t pfa_bitmap_positions(const uint64_t* words, uint32_t n_tiles, uint32_t words_per_tile,
+                             uint32_t tile_sites, uint32_t n_sites, uint32_t* pos_out, uint64_t cap);
+
+/* ---- codon-set classifier on the host (same code as the device path) --------
+ * `mask`: bit (16*e0 + 4*e1 + e2) set for each distinct codon, bases encoded
+ * A=0, C=1, T=2, G=3 (= (ascii >> 1) & 3).  Returns bits 0-2 = codon positions
+ * called synonymous, bits 3-5 = non-synonymous (PolyFastA.py:319-434). */
+uint32_t pfa_classify_codon_mask(uint64_t mask);
+/* synonymous single-nucleotide neighbours (0..4) of one codon = 3 x syncodfreq
+ * (PolyFastA.py:536-557) */
+uint32_t pfa_codon_syn_thirds(uint32_t codon);
+
+/* ---- synthetic alignments (bench / tests; polyfasta_amd/synth.py is the spec) */
+typedef struct pfa_synth_params {
+  uint64_t seed;
+  uint64_t first_aln;     /* alignment index of matrix 0                          */
+  uint32_t n_aln;         /* number of consecutive matrices                       */
+  uint32_t n_rows;
+  uint32_t n_sites;
+  uint32_t row_stride;    /* bytes; matrix m starts at m * n_rows * row_stride    */
+  uint32_t seg_thresh;    /* of 2^24                                              */
+  uint32_t tri_thresh;    /* of 2^10                                              */
+  uint32_t n_units;
+  uint32_t coding;        /* 1: ancestral codons uniform over the 61 sense codons */
+} pfa_synth_params;
+int pfa_synth_fill_dev(uint8_t* d_bases, const pfa_synth_params* p,
+                       const uint32_t* cdf, const uint32_t* units);
+int pfa_synth_fill_host(uint8_t* bases, const pfa_synth_params* p,
+                        const uint32_t* cdf, const uint32_t* units);
+
+/* ---- FASTA packer (host, readfasta semantics PolyFastA.py:227-250) ----------
+ * Parses FASTA text into a row-major upper-case byte matrix.
+ * Pass 1: pfa_fasta_index() reports the records; pass 2: pfa_fasta_pack()
+ * writes them with the given row stride.  A repeated header resets its record
+ * but keeps its first position (dict semantics). */
+typedef struct pfa_fasta_rec {
+  uint64_t name_off; /* into text: header without '>' and trailing whitespace */
+  uint32_t name_len;
+  uint32_t seq_len;  /* bytes after rstrip() of every sequence line           */
+  uint64_t first_line_off; /* offset of the first sequence line of the LAST occurrence */
+  uint64_t end_off;        /* offset just past this record's last line               */
+} pfa_fasta_rec;
+/* returns number of records (>= 0), PFA_ERR_FORMAT if no header line was seen
+ * (the reference's "is not FASTA" case, PolyFastA.py:246-248) */
+int64_t pfa_fasta_index(const uint8_t* text, uint64_t n_text, pfa_fasta_rec* recs, uint64_t cap);
+int pfa_fasta_pack(const uint8_t* text, uint64_t n_text, const pfa_fasta_rec* recs, uint64_t n_recs,
+                   uint8_t* bases_out, uint32_t row_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFA_H */

@@ -1,0 +1,169 @@
+"""ctypes binding of libpfa_hip.so (include/pfa.h).
+
+The library is the product: there is no CPU fallback.  ``load()`` raises
+``PfaLibraryError`` when the shared object has not been built, and ``init()``
+raises when no gfx950 device is visible.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpfa_hip.so")
+
+PFA_ABI_VERSION = 1
+PFA_NO_ROW_IDX = 0xFFFFFFFF
+PFA_FLAG_CDS = 1
+PFA_WANT_VAR_BITMAP = 1
+PFA_WANT_SN_BITMAP = 2
+PFA_SYN_BINS = 65
+PFA_MAX_ROWS = 2048
+PFA_ERR_FORMAT = -7
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+u32p = ctypes.POINTER(ctypes.c_uint32)
+u64p = ctypes.POINTER(ctypes.c_uint64)
+
+# numpy mirrors of the C structs (layout checked against sizeof in tests)
+DESC_DTYPE = np.dtype([
+    ("base_off", "<u8"), ("n_rows", "<u4"), ("n_sites", "<u4"), ("row_stride", "<u4"),
+    ("row_idx_off", "<u4"), ("flags", "<u4"), ("sfs_off", "<u4"), ("tile_off", "<u4"),
+    ("mat_rows", "<u4"),
+], align=True)
+RESULT_DTYPE = np.dtype([
+    ("H", "<u8"), ("H_S", "<u8"), ("H_N", "<u8"), ("seg_sites", "<u4"), ("sfs_bad", "<u4"),
+    ("seg_S", "<u4"), ("seg_N", "<u4"), ("nstops", "<u4"), ("missing_cols", "<u4"),
+    ("status", "<u4"), ("reserved", "<u4"),
+], align=True)
+FASTA_REC_DTYPE = np.dtype([
+    ("name_off", "<u8"), ("name_len", "<u4"), ("seq_len", "<u4"),
+    ("first_line_off", "<u8"), ("end_off", "<u8"),
+], align=True)
+assert DESC_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 56 and FASTA_REC_DTYPE.itemsize == 32
+
+
+class SynthParamsC(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("first_aln", ctypes.c_uint64), ("n_aln", ctypes.c_uint32),
+                ("n_rows", ctypes.c_uint32), ("n_sites", ctypes.c_uint32), ("row_stride", ctypes.c_uint32),
+                ("seg_thresh", ctypes.c_uint32), ("tri_thresh", ctypes.c_uint32), ("n_units", ctypes.c_uint32),
+                ("coding", ctypes.c_uint32)]
+
+
+class PfaLibraryError(RuntimeError):
+    pass
+
+
+class PfaError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libpfa_hip error {code}: {message}")
+        self.code = code
+
+
+# every symbol include/pfa.h declares: (restype, argtypes)
+_vp = ctypes.c_void_p
+_PROTOTYPES = {
+    "pfa_abi_version": (ctypes.c_int, []),
+    "pfa_device_count": (ctypes.c_int, []),
+    "pfa_init": (ctypes.c_int, [ctypes.c_int]),
+    "pfa_shutdown": (None, []),
+    "pfa_last_error": (ctypes.c_char_p, []),
+    "pfa_sync": (ctypes.c_int, []),
+    "pfa_dev_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "pfa_dev_free": (ctypes.c_int, [_vp]),
+    "pfa_upload": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "pfa_download": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "pfa_tile_sites": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_uint32]),
+    "pfa_var_words_per_tile": (ctypes.c_uint32, [ctypes.c_uint32]),
+    "pfa_sn_words_per_tile": (ctypes.c_uint32, [ctypes.c_uint32]),
+    "pfa_plan_create": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp, ctypes.c_size_t, ctypes.c_uint64,
+                                       ctypes.c_uint32, ctypes.POINTER(_vp)]),
+    "pfa_plan_run": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+    "pfa_plan_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
+    "pfa_plan_fetch": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pfa_plan_results_dev": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_size_t)]),
+    "pfa_plan_n_tiles": (ctypes.c_uint32, [_vp]),
+    "pfa_plan_tiles_per_chunk": (ctypes.c_uint32, [_vp]),
+    "pfa_plan_lds_bytes": (ctypes.c_uint32, [_vp]),
+    "pfa_plan_sfs_words": (ctypes.c_uint64, [_vp]),
+    "pfa_plan_destroy": (None, [_vp]),
+    "pfa_scan_batch": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint32, _vp, ctypes.c_size_t,
+                                      _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pfa_bitmap_positions": (ctypes.c_int64, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                              ctypes.c_uint32, _vp, ctypes.c_uint64]),
+    "pfa_classify_codon_mask": (ctypes.c_uint32, [ctypes.c_uint64]),
+    "pfa_codon_syn_thirds": (ctypes.c_uint32, [ctypes.c_uint32]),
+    "pfa_synth_fill_dev": (ctypes.c_int, [_vp, ctypes.POINTER(SynthParamsC), _vp, _vp]),
+    "pfa_synth_fill_host": (ctypes.c_int, [_vp, ctypes.POINTER(SynthParamsC), _vp, _vp]),
+    "pfa_fasta_index": (ctypes.c_int64, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint64]),
+    "pfa_fasta_pack": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint64, _vp, ctypes.c_uint32]),
+}
+
+_lib = None
+_device = None
+
+
+def load():
+    """dlopen libpfa_hip.so and bind every prototype (works without a GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PfaLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m polyfasta_amd._build` "
+            "(hipcc, gfx950).  polyfasta_amd has no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover
+        raise PfaLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (restype, argtypes) in _PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.pfa_abi_version() != PFA_ABI_VERSION:
+        raise PfaLibraryError("libpfa_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return (load().pfa_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc < 0:
+        raise PfaError(rc, last_error())
+    return rc
+
+
+def init(device=None):
+    """Bind this process to one GPU (default: LOCAL_RANK or 0).  Raises without a gfx950 device."""
+    global _device
+    lib = load()
+    if device is None:
+        device = _device if _device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+        ndev = lib.pfa_device_count()
+        if ndev > 0:
+            device %= ndev
+    if _device == device:
+        return device
+    check(lib.pfa_init(int(device)))
+    _device = device
+    return device
+
+
+def shutdown():
+    global _device
+    if _lib is not None:
+        _lib.pfa_shutdown()
+    _device = None
+
+
+def ptr(arr):
+    """void* of a C-contiguous numpy array (None -> NULL)."""
+    if arr is None:
+        return None
+    assert arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(ctypes.c_void_p)

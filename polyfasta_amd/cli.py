@@ -1,0 +1,186 @@
+"""Command line of polyfasta_amd: the PolyFastA.py surface (``--file/--dir/--pops/
+--out/--pipe/--cds/--silent/--name/--jc``, same CSV columns and comment lines),
+driven by batched GPU scans.
+
+Mirrors ``main`` (PolyFastA.py:13-142), ``print_result`` / ``no_header``
+(:147-198) and ``print_header`` (:211-225).  Differences, all deliberate:
+  * files are parsed, packed and scanned in batches (one kernel launch per
+    batch) instead of one at a time; output order is unchanged (sorted paths x
+    population order as typed);
+  * ``--pops`` works: the reference crashes on Python 3 at :126
+    (``len(filter(...))``); the intended behaviour is implemented (App. A-1 of
+    SURVEY.md): substring match of each key in the headers, one row per key;
+  * every scan runs on the GPU; there is no CPU path.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from . import fasta, stats
+from .scan import Batch, scan_batch
+
+HEADER_PLAIN = "file,seqlen,pop,N,seg_sites,pi,theta,tajimasD"
+HEADER_CDS = ("file,sites_S,sites_N,pop,N,seg_sites_S,seg_sites_N,pi_S,pi_N,theta_S,theta_N,"
+              "tajimasD_S,tajimasD_N,nstops")
+NO_VAR = "0,0,0,NA"
+
+# batches are cut when the packed bases exceed this many bytes
+BATCH_BYTES = 1 << 30
+
+
+def format_plain_row(name, pop, n_rows, seqlen, res, jc):
+    """One non-coding CSV row from a device record (PolyFastA.py:182-198)."""
+    s = int(res["seg_sites"])
+    if s == 0:
+        return f"{name},{seqlen},{pop},{n_rows},{NO_VAR}"
+    p = stats.finish_polymorphism(s, int(res["H"]), n_rows, seqlen, jc)
+    return f"{name},{seqlen},{pop},{n_rows},{p[0]},{p[1]},{p[2]},{p[3]}"
+
+
+def format_cds_row(name, pop, n_rows, seqlen, res, syn_num, jc):
+    """One coding CSV row (PolyFastA.py:151-180), including the reference's
+    mis-ordered no-variation row (:160-162)."""
+    ssites = stats.syn_sites_from_bins(syn_num)
+    nsites = (seqlen - 3 * int(res["missing_cols"])) - ssites
+    if int(res["seg_sites"]) == 0:
+        return f"{name},{round(ssites, 2)},{round(nsites, 2)},{pop},{n_rows},{NO_VAR},{NO_VAR},{0}"
+    ps = stats.finish_polymorphism(int(res["seg_S"]), int(res["H_S"]), n_rows, ssites, jc)
+    pn = stats.finish_polymorphism(int(res["seg_N"]), int(res["H_N"]), n_rows, nsites, jc)
+    return (f"{name},{round(ssites, 2)},{round(nsites, 2)},{pop},{n_rows},{ps[0]},{pn[0]},{ps[1]},{pn[1]},"
+            f"{ps[2]},{pn[2]},{ps[3]},{pn[3]},{int(res['nstops'])}")
+
+
+class Sink:
+    """stdout, or append-to-file with the reference's progress chatter."""
+
+    def __init__(self, out, silent):
+        self.out, self.silent = out, silent
+
+    def header(self, cds):
+        if self.silent:
+            return
+        text = HEADER_CDS if cds else HEADER_PLAIN
+        if self.out:
+            with open(self.out, "w") as o:      # PolyFastA.py:103 -> :215/:222 ("w")
+                o.write(text + "\n")
+        else:
+            print(text)
+
+    def comment(self, text):
+        if self.out:
+            with open(self.out, "a") as o:
+                o.write(text + "\n")
+        else:
+            print(text)
+
+    def row(self, text, name, pop):
+        if self.out:
+            with open(self.out, "a") as o:
+                if not self.silent:
+                    print("\r", f"Writting to {self.out}, pop: {pop:<10s}, parsing: {name:<15s}", end="", flush=True)
+                o.write(text + "\n")
+        else:
+            print(text)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(
+        prog="polyfasta_amd", formatter_class=argparse.RawTextHelpFormatter,
+        description="GPU (MI355X) estimator of nucleotide diversity (theta_pi), Watterson's theta (theta_w)\n"
+                    "and Tajima's D for coding and non-coding alignments; PolyFastA.py-compatible.",
+        epilog="Examples:\n"
+               "  python -m polyfasta_amd -f aln.fas -p pop1,pop2        rows per population (header substring)\n"
+               "  python -m polyfasta_amd -f aln.fas -p pop1,pop2 --cds --jc\n"
+               "  python -m polyfasta_amd -d fastaDir/ --out all.csv\n"
+               "  python -m polyfasta_amd --pipe -p pop1,pop2 < aln.fas\n")
+    p.add_argument("--file", "-f", nargs="*", type=str, default="", help="one or several alignment files in FASTA format.")
+    p.add_argument("--dir", "-d", type=str, default=".", help="directory containing FASTA files only.")
+    p.add_argument("--pops", "-p", nargs="?", default=False, metavar="pop1,pop2,pop3", type=str,
+                   help="split alignment by populations: comma-separated strings found in the sequence headers.")
+    p.add_argument("--out", "-o", type=str, default="", help="name of output file (default: print to screen).")
+    p.add_argument("--pipe", "-i", action="store_true", default=False, help="read one FASTA alignment from STDIN.")
+    p.add_argument("--cds", "-c", action="store_true", default=False,
+                   help="the alignment is protein coding: split into synonymous and nonsynonymous sites.")
+    p.add_argument("--silent", "-s", action="store_true", default=False, help="suppress header and verbose output.")
+    p.add_argument("--name", "-n", type=str, default=False, help="name of the DNA region to show in output.")
+    p.add_argument("--jc", action="store_true", default=False, help="Jukes-Cantor correction for Pi.")
+    return p
+
+
+def _flush(batch, pending, sink, cds, jc):
+    """Scan the batch and emit the pending events in order."""
+    out = scan_batch(batch) if batch.n_units else None
+    for ev in pending:
+        if ev[0] == "comment":
+            sink.comment(ev[1])
+        elif ev[0] == "stdout":
+            print(ev[1])
+        else:
+            _, unit, name, pop, n_rows, seqlen = ev
+            res = out.results[unit]
+            text = (format_cds_row(name, pop, n_rows, seqlen, res, out.syn_num[unit], jc) if cds
+                    else format_plain_row(name, pop, n_rows, seqlen, res, jc))
+            sink.row(text, name, pop)
+
+
+def main(argv=None):
+    parser = build_parser()
+    args = parser.parse_args(argv)
+
+    if args.file == "" and args.dir == "." and not args.pipe:                      # PolyFastA.py:84-88
+        print("Both --file/-f and --dir/-d were not found.")
+        r = input("Do you wish to run polySFS on all files in the current directory? [y|n]: ")
+        if r != "y":
+            parser.error(parser.print_help())
+    if len(args.file) != 0 and args.dir != ".":                                    # :90-91
+        parser.error("Run with either --file/-f or --dir/-d, but not both")
+    elif len(args.file) == 0 and args.dir != ".":                                  # :93-94
+        args.file = [args.dir + "/" + i for i in os.listdir(args.dir)]
+    elif len(args.file) == 0 and args.dir == "." and args.pipe:                    # :96-100
+        args.file = ["stdin"] if not args.name else [args.name]
+
+    sink = Sink(args.out, args.silent)
+    sink.header(args.cds)                                                          # :102-103
+
+    batch, pending = Batch(), []
+    for path in sorted(args.file):                                                 # :104
+        if len(args.file) > 0 and args.pipe and not (args.file[0] == "stdin" or args.file[0] == args.name):
+            parser.error("A FASTA file or multiple files cannot be used with the --pipe argument.")
+        aln = fasta.read_fasta_stdin() if args.pipe else fasta.read_fasta_file(path)
+        if aln is None:
+            pending.append(("stdout", f"# file {path} is not FASTA!"))              # :247 (always stdout)
+            continue
+        name = path.split("/")[-1]                                                 # :110
+        if not aln.same_length:
+            pending.append(("comment", f"# Sequences do not have the same length: {name}"))   # :135-140
+            continue
+        seqlen = int(aln.seq_lens[0])
+        if args.cds and seqlen % 3 != 0:                                           # :114-119
+            pending.append(("comment", f"# CDS sequence length is not a multiple of 3: {name}"))
+        mid = batch.add_matrix(aln.matrix)
+        if not args.pops:                                                          # :120-121
+            unit = batch.add_unit(mid, cds=args.cds)
+            pending.append(("unit", unit, name, "NA", aln.n_rows, seqlen))
+        else:
+            for pop in args.pops.split(","):                                       # :123-134
+                rows = [i for i, h in enumerate(aln.names) if pop in h]
+                if len(rows) == 0:
+                    pending.append(("comment", f"# Pop {pop} string was not found in fasta headers."))
+                    continue
+                unit = batch.add_unit(mid, rows=np.asarray(rows, dtype=np.uint32), cds=args.cds)
+                pending.append(("unit", unit, name, pop, len(rows), seqlen))
+        if batch.nbytes >= BATCH_BYTES:
+            _flush(batch, pending, sink, args.cds, args.jc)
+            batch, pending = Batch(), []
+    _flush(batch, pending, sink, args.cds, args.jc)
+    if len(args.out) != 0 and not args.silent:                                     # :141-142
+        print("")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,41 @@
+// pfa_common.h — context, error plumbing and small helpers shared by the
+// translation units of libpfa_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pfa.h"
+
+namespace pfa {
+
+struct Context {
+  bool ready = false;
+  int device = -1;
+  int n_cu = 0;
+  size_t lds_per_block = 0;
+  hipStream_t stream = nullptr;
+};
+
+Context& ctx();
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+}  // namespace pfa
+
+#define PFA_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      pfa::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                     __LINE__);                                                        \
+      return PFA_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+#define PFA_NEED_INIT()                                              \
+  do {                                                               \
+    if (!pfa::ctx().ready) {                                         \
+      pfa::set_error("pfa_init() has not been called successfully"); \
+      return PFA_ERR_NOT_INIT;                                       \
+    }                                                                \
+  } while (0)

@@ -1,0 +1,893 @@
+// pfa_scan.hip — the polymorphism-scan kernels of libpfa_hip.so (gfx950 only)
+// and the plan / launch entry points of include/pfa.h.
+//
+// What is computed (all integers), per scan unit of N rows:
+//   S      = number of site columns with more than one distinct byte   PolyFastA.py:252-261
+//   H      = sum over those columns of (N^2 - sum_j c_j^2)              PolyFastA.py:485-492
+//   SFS    = histogram of the second-largest A/C/G/T allele count        PolyFastA.py:274-282
+//   coding = per codon column the set of distinct clean codons -> nstops,
+//            missing columns, synonymous-site numerators, and the S / N label
+//            of each variable codon position with the H of its site       PolyFastA.py:284-315,319-434
+//
+// Kernel shape.  One 64-lane wavefront per workgroup; no
+// inter-wave synchronisation anywhere.  A wavefront owns a chunk of
+// consecutive column tiles of one unit.  Per tile:
+//   stage   N rows x 64*LB sites -> LDS with LDS-DMA (global_load_lds_dwordx4,
+//           one KiB per instruction, no VGPR round trip); each instruction
+//           covers 1024/(64*LB) rows so every lane moves 16 contiguous bytes
+//   tier 1  lane = LB adjacent sites; walk the rows with one conflict-free
+//           ds_read per row, keep running AND / OR of the bytes: a site is
+//           monomorphic iff AND == OR (2 VALU ops per row per lane)
+//   compact ballot + mbcnt turn the per-lane flags into a dense list of the
+//           tile's variable sites (typically ~4 % of the sites)
+//   tier 2  4 lanes per variable site walk the column out of LDS, count
+//           A C G T - N with compare/add-carry, butterfly-reduce with two
+//           lane shuffles; any other byte takes an exact generic path
+//           (sum_i #{j : x_j = x_i}); H, SFS bin (LDS histogram), bitmaps
+//   coding  4 lanes per variable codon column OR a 64-bit codon-presence mask
+//           down the rows; the classifier runs on the mask (pfa_codon.h)
+// Per-chunk partial sums leave through integer atomics (order-independent).
+#include <algorithm>
+#include <cstdarg>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "pfa_codon.h"
+#include "pfa_common.h"
+
+namespace pfa {
+
+Context& ctx() {
+  static Context c;
+  return c;
+}
+
+static thread_local char g_err[768] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static constexpr ct::Tables kHostTables = ct::make_tables();
+
+}  // namespace pfa
+
+__constant__ pfa::ct::Tables d_tables = pfa::ct::make_tables();
+
+namespace pfa {
+
+// ---------------------------------------------------------------- geometry
+template <int LB>
+struct Geo {
+  static constexpr uint32_t WW = 64u * LB;            // sites (= bytes) per LDS tile row
+  static constexpr uint32_t LPR = WW / 16u;           // DMA lanes per row
+  static constexpr uint32_t RPI = 64u / LPR;          // rows per DMA instruction
+  static constexpr uint32_t TW_CDS = (WW / 48u) * 48u;  // whole codons, 16-byte aligned tile start
+  static constexpr uint32_t NCOD = TW_CDS / 3u;
+  static constexpr uint32_t CPASS = (NCOD + 63u) / 64u;
+};
+
+struct LdsLayout {
+  uint32_t tile, list, hist, rowmap, hsite, clist, lab, synhist, total;
+};
+
+PFA_HD inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
+
+PFA_HD inline LdsLayout lds_layout(uint32_t lb, uint32_t n_max, bool cds) {
+  const uint32_t ww = 64u * lb, rpi = 1024u / ww;
+  const uint32_t n = n_max ? n_max : 1u;
+  LdsLayout o;
+  o.tile = 0;
+  o.list = ((n + rpi - 1u) / rpi) * 1024u;
+  o.hist = o.list + ww;
+  o.rowmap = o.hist + round16((n / 2u) * 4u + 4u);
+  o.hsite = o.rowmap + round16(n * 4u);
+  o.clist = o.hsite + (cds ? ww * 4u : 0u);
+  o.lab = o.clist + (cds ? 128u : 0u);
+  o.synhist = o.lab + (cds ? 128u : 0u);
+  o.total = o.synhist + (cds ? round16(PFA_SYN_BINS * 4u) : 0u);
+  return o;
+}
+
+struct ScanArgs {
+  const uint8_t* bases;
+  const pfa_desc* descs;
+  const uint32_t* row_idx;
+  pfa_result* results;
+  uint32_t* sfs;
+  uint32_t* syn_num;
+  unsigned long long* var_bm;
+  unsigned long long* syn_bm;
+  unsigned long long* non_bm;
+  uint32_t n_desc;
+  uint32_t tiles_per_chunk;
+  uint32_t n_max;
+  uint32_t pad;
+};
+
+// ---------------------------------------------------------------- device helpers
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ inline uint32_t mbcnt64(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+}
+__device__ inline uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ inline unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ inline uint32_t quad_sum(uint32_t v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  return v;
+}
+__device__ inline unsigned long long quad_or(unsigned long long v) {
+  v |= __shfl_xor(v, 1);
+  v |= __shfl_xor(v, 2);
+  return v;
+}
+__device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ inline uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+// codon of three bytes: index, or -1 when any byte is not exactly A/C/G/T (PolyFastA.py:301)
+__device__ inline int codon_of(uint32_t x0, uint32_t x1, uint32_t x2) {
+  const bool ok = base_clean(x0) && base_clean(x1) && base_clean(x2);
+  return ok ? int(base_code(x0) * 16u + base_code(x1) * 4u + base_code(x2)) : -1;
+}
+
+// ---------------------------------------------------------------- the kernel
+template <int LB, bool USE_DMA, bool HAS_CDS>
+__global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
+  using G = Geo<LB>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+  const uint32_t lane = threadIdx.x;
+  const pfa_desc D = A.descs[blockIdx.x];
+  const bool cds = HAS_CDS && (D.flags & PFA_FLAG_CDS) != 0u;
+  const uint32_t TW = cds ? G::TW_CDS : G::WW;
+  const uint32_t N = D.n_rows, L = D.n_sites;
+  if (N == 0u || L == 0u) return;
+  const uint32_t n_tiles = (L + TW - 1u) / TW;
+  const uint32_t t0 = blockIdx.y * A.tiles_per_chunk;
+  if (t0 >= n_tiles) return;
+  const uint32_t t1 = umin(t0 + A.tiles_per_chunk, n_tiles);
+
+  const LdsLayout lo = lds_layout(LB, A.n_max, HAS_CDS);
+  uint8_t* const tile8 = lds + lo.tile;
+  uint8_t* const list = lds + lo.list;
+  uint32_t* const hist = reinterpret_cast<uint32_t*>(lds + lo.hist);
+  uint32_t* const rowmap = reinterpret_cast<uint32_t*>(lds + lo.rowmap);
+  uint32_t* const hsite = reinterpret_cast<uint32_t*>(lds + lo.hsite);
+  uint8_t* const clist = lds + lo.clist;
+  uint8_t* const lab = lds + lo.lab;
+  uint32_t* const synhist = reinterpret_cast<uint32_t*>(lds + lo.synhist);
+
+  const uint32_t nbins = N / 2u;
+  for (uint32_t i = lane; i < N; i += 64u)
+    rowmap[i] = D.row_idx_off != PFA_NO_ROW_IDX ? A.row_idx[D.row_idx_off + i] : i;
+  for (uint32_t i = lane; i < nbins; i += 64u) hist[i] = 0u;
+  if (cds)
+    for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) synhist[i] = 0u;
+  __syncthreads();
+
+  // per-lane partial sums of this chunk
+  uint32_t acc_S = 0u, acc_bad = 0u;
+  unsigned long long acc_H = 0ull;
+  uint32_t acc_segS = 0u, acc_segN = 0u, acc_stops = 0u, acc_missing = 0u, acc_syn1 = 0u;
+  unsigned long long acc_HS = 0ull, acc_HN = 0ull;
+
+  const uint8_t* const mat = A.bases + D.base_off;
+  const uint32_t n_inst = (N + G::RPI - 1u) / G::RPI;
+  const uint32_t NN = N * N;
+
+  for (uint32_t tile = t0; tile < t1; ++tile) {
+    const uint32_t site0 = tile * TW;
+    const uint32_t lim = umin(TW, L - site0);  // valid sites of this tile
+
+    // ---------------- stage the column tile into LDS
+    {
+      const uint32_t c = lane % G::LPR, rr = lane / G::LPR;
+      const uint32_t col = umin(site0 + 16u * c, D.row_stride - 16u);
+      if constexpr (USE_DMA) {
+        for (uint32_t g = 0; g < n_inst; ++g) {
+          const uint32_t r = umin(g * G::RPI + rr, N - 1u);
+          const uint8_t* src = mat + (uint64_t)rowmap[r] * D.row_stride + col;
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+#pragma unroll 4
+        for (uint32_t g = 0; g < n_inst; ++g) {
+          const uint32_t r = umin(g * G::RPI + rr, N - 1u);
+          const uint4 v = *reinterpret_cast<const uint4*>(mat + (uint64_t)rowmap[r] * D.row_stride + col);
+          *reinterpret_cast<uint4*>(tile8 + g * 1024u + lane * 16u) = v;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---------------- tier 1: running AND / OR down the rows
+    uint32_t va = 0xFFFFFFFFu, vo = 0u;
+    if constexpr (LB == 4) {
+      const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile8);
+#pragma unroll 8
+      for (uint32_t r = 0; r < N; ++r) {
+        const uint32_t x = t32[r * 64u + lane];
+        va &= x;
+        vo |= x;
+      }
+    } else {
+      va = 0xFFu;
+#pragma unroll 8
+      for (uint32_t r = 0; r < N; ++r) {
+        const uint32_t x = tile8[r * 64u + lane];
+        va &= x;
+        vo |= x;
+      }
+    }
+    const uint32_t vd = va ^ vo;
+
+    // ---------------- compact the variable sites of the tile
+    uint32_t P = 0u;
+#pragma unroll
+    for (uint32_t b = 0; b < (uint32_t)LB; ++b) {
+      const uint32_t off = LB * lane + b;
+      const bool pb = ((vd >> (8u * b)) & 0xFFu) != 0u && off < lim;
+      const uint64_t m = __ballot(pb);
+      if (pb) list[P + mbcnt64(m)] = uint8_t(off);
+      if (A.var_bm != nullptr && lane == 0u)
+        A.var_bm[(uint64_t)(D.tile_off + tile) * LB + b] = m;
+      P += (uint32_t)__popcll(m);
+    }
+    P = __builtin_amdgcn_readfirstlane(P);
+    acc_S += (lane == 0u) ? P : 0u;
+    if (cds) {
+#pragma unroll
+      for (uint32_t b = 0; b < (uint32_t)LB; ++b) hsite[LB * lane + b] = 0u;
+    }
+    __syncthreads();
+
+    // ---------------- tier 2: exact allele counts of the variable sites
+    const uint32_t slot = lane >> 2, ph = lane & 3u;
+    for (uint32_t p0 = 0; p0 < P; p0 += 16u) {
+      const uint32_t idx = p0 + slot;
+      const bool act = idx < P;
+      const uint32_t s = list[act ? idx : 0u];
+      const uint8_t* colp = tile8 + s;
+      uint32_t cA = 0, cC = 0, cG = 0, cT = 0, cGap = 0, cNn = 0;
+#pragma unroll 4
+      for (uint32_t r = ph; r < N; r += 4u) {
+        const uint32_t x = colp[r * G::WW];
+        cA += (x == 'A');
+        cC += (x == 'C');
+        cG += (x == 'G');
+        cT += (x == 'T');
+        cGap += (x == '-');
+        cNn += (x == 'N');
+      }
+      cA = quad_sum(cA);
+      cC = quad_sum(cC);
+      cG = quad_sum(cG);
+      cT = quad_sum(cT);
+      cGap = quad_sum(cGap);
+      cNn = quad_sum(cNn);
+      uint32_t sumsq = cA * cA + cC * cC + cG * cG + cT * cT + cGap * cGap + cNn * cNn;
+      const uint32_t n_other = N - (cA + cC + cG + cT + cGap + cNn);
+      if (__any(act && n_other != 0u)) {
+        // exact path for any other byte value: sum over such rows i of #{j : x_j == x_i}
+        uint32_t extra = 0u;
+        if (act && n_other != 0u) {
+          for (uint32_t i = ph; i < N; i += 4u) {
+            const uint32_t xi = colp[i * G::WW];
+            const bool six = xi == 'A' || xi == 'C' || xi == 'G' || xi == 'T' || xi == '-' || xi == 'N';
+            if (!six) {
+              uint32_t cnt = 0u;
+              for (uint32_t j = 0; j < N; ++j) cnt += (colp[j * G::WW] == xi);
+              extra += cnt;
+            }
+          }
+        }
+        sumsq += quad_sum(extra);
+      }
+      if (act && ph == 0u) {
+        const uint32_t hs = NN - sumsq;
+        acc_H += hs;
+        if (cds) hsite[s] = hs;
+        // second-largest A/C/G/T count (PolyFastA.py:279-281)
+        const uint32_t hi1 = umax(cA, cC), lo1 = umin(cA, cC), hi2 = umax(cG, cT), lo2 = umin(cG, cT);
+        const uint32_t second = umax(umin(hi1, hi2), umax(lo1, lo2));
+        if (second == 0u) acc_bad += 1u;
+        else atomicAdd(&hist[second - 1u], 1u);
+      }
+    }
+
+    // ---------------- coding sequences: codon columns of the tile
+    if (cds) {
+      __syncthreads();
+      uint32_t PC = 0u;
+#pragma unroll
+      for (uint32_t pass = 0; pass < G::CPASS; ++pass) {
+        const uint32_t cc = pass * 64u + lane;
+        const uint32_t s0 = 3u * cc;
+        const bool exists = cc < G::NCOD && s0 < lim;
+        const bool full = exists && (s0 + 2u < lim || site0 + s0 + 2u < L);
+        bool isvar = false;
+        if (exists && !full) acc_missing += 1u;     // partial last codon (PolyFastA.py:301-305)
+        if (full) {
+          isvar = (hsite[s0] | hsite[s0 + 1u] | hsite[s0 + 2u]) != 0u;
+          if (!isvar) {
+            const int code = codon_of(tile8[s0], tile8[s0 + 1u], tile8[s0 + 2u]);
+            if (code < 0) acc_missing += 1u;
+            else {
+              acc_syn1 += d_tables.syn3[code];
+              acc_stops += (d_tables.stop_mask >> code) & 1u;
+            }
+          }
+        }
+        if (cc < 128u) lab[cc] = 0u;
+        const uint64_t m = __ballot(isvar);
+        if (isvar) clist[PC + mbcnt64(m)] = uint8_t(cc);
+        PC += (uint32_t)__popcll(m);
+      }
+      PC = __builtin_amdgcn_readfirstlane(PC);
+      __syncthreads();
+      for (uint32_t p0 = 0; p0 < PC; p0 += 16u) {
+        const uint32_t idx = p0 + slot;
+        const bool act = idx < PC;
+        const uint32_t cc = clist[act ? idx : 0u];
+        const uint32_t s0 = 3u * cc;
+        const uint8_t* colp = tile8 + s0;
+        unsigned long long M = 0ull;
+        for (uint32_t r = ph; r < N; r += 4u) {
+          const uint8_t* q = colp + r * G::WW;
+          const int code = codon_of(q[0], q[1], q[2]);
+          if (code >= 0) M |= 1ull << code;
+        }
+        M = quad_or(M);
+        if (act && ph == 0u) {
+          const uint32_t k = (uint32_t)__popcll(M);
+          if (k == 0u) acc_missing += 1u;
+          else {
+            atomicAdd(&synhist[k], syn_thirds_of_mask(M, d_tables));
+            acc_stops += (M & d_tables.stop_mask) != 0ull;
+            const uint32_t labels = classify_sense_mask(M & ~d_tables.stop_mask, d_tables);
+#pragma unroll
+            for (uint32_t p = 0; p < 3u; ++p) {
+              const uint32_t hs = hsite[s0 + p];
+              if ((labels >> p) & 1u) { acc_segS += 1u; acc_HS += hs; }
+              if ((labels >> (3u + p)) & 1u) { acc_segN += 1u; acc_HN += hs; }
+            }
+            lab[cc] = uint8_t(labels);
+          }
+        }
+      }
+      if (A.syn_bm != nullptr) {
+        __syncthreads();
+#pragma unroll
+        for (uint32_t pass = 0; pass < G::CPASS; ++pass) {
+          const uint32_t cc = pass * 64u + lane;
+          const uint32_t lb = cc < G::NCOD ? lab[cc] : 0u;
+          const uint64_t w = (uint64_t)(D.tile_off + tile) * (3u * G::CPASS) + pass * 3u;
+#pragma unroll
+          for (uint32_t p = 0; p < 3u; ++p) {
+            const uint64_t ms = __ballot((lb >> p) & 1u);
+            const uint64_t mn = __ballot((lb >> (3u + p)) & 1u);
+            if (lane == 0u) { A.syn_bm[w + p] = ms; A.non_bm[w + p] = mn; }
+          }
+        }
+      }
+    }
+    __syncthreads();  // tile buffer is reused by the next iteration
+  }
+
+  // ---------------- flush the chunk's partial sums
+  pfa_result* R = A.results + blockIdx.x;
+  acc_S = wave_sum(acc_S);
+  acc_bad = wave_sum(acc_bad);
+  acc_H = wave_sum(acc_H);
+  if (cds) {
+    acc_segS = wave_sum(acc_segS);
+    acc_segN = wave_sum(acc_segN);
+    acc_stops = wave_sum(acc_stops);
+    acc_missing = wave_sum(acc_missing);
+    acc_syn1 = wave_sum(acc_syn1);
+    acc_HS = wave_sum(acc_HS);
+    acc_HN = wave_sum(acc_HN);
+  }
+  if (lane == 0u) {
+    if (acc_S) atomicAdd(&R->seg_sites, acc_S);
+    if (acc_bad) atomicAdd(&R->sfs_bad, acc_bad);
+    if (acc_H) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H), acc_H);
+    if (cds) {
+      if (acc_segS) atomicAdd(&R->seg_S, acc_segS);
+      if (acc_segN) atomicAdd(&R->seg_N, acc_segN);
+      if (acc_stops) atomicAdd(&R->nstops, acc_stops);
+      if (acc_missing) atomicAdd(&R->missing_cols, acc_missing);
+      if (acc_HS) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H_S), acc_HS);
+      if (acc_HN) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H_N), acc_HN);
+      if (acc_syn1) atomicAdd(&A.syn_num[(uint64_t)blockIdx.x * PFA_SYN_BINS + 1u], acc_syn1);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = lane; i < nbins; i += 64u) {
+    const uint32_t v = hist[i];
+    if (v) atomicAdd(&A.sfs[D.sfs_off + i], v);
+  }
+  if (cds) {
+    for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) {
+      const uint32_t v = synhist[i];
+      if (v) atomicAdd(&A.syn_num[(uint64_t)blockIdx.x * PFA_SYN_BINS + i], v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- plans
+static constexpr uint32_t kMaxRowsWide = 600u;  // LB = 4 (256-site tiles) up to here, LB = 1 above
+static constexpr int kEventRing = 64;
+
+}  // namespace pfa
+
+struct pfa_plan {
+  uint32_t n_desc = 0;
+  uint32_t lb = 4;
+  uint32_t n_max = 0;
+  uint32_t max_tiles = 0;
+  uint32_t n_tiles_total = 0;
+  uint32_t tiles_per_chunk = 1;
+  uint32_t n_chunks = 1;
+  uint32_t want = 0;
+  bool any_cds = false;
+  uint64_t sfs_words = 0;
+  uint64_t n_bases_bytes = 0;
+  uint32_t lds_bytes = 0;
+  pfa_desc* d_descs = nullptr;
+  uint32_t* d_row_idx = nullptr;
+  pfa_result* d_results = nullptr;
+  uint32_t* d_sfs = nullptr;
+  uint32_t* d_syn = nullptr;
+  unsigned long long* d_var_bm = nullptr;
+  unsigned long long* d_syn_bm = nullptr;
+  unsigned long long* d_non_bm = nullptr;
+  hipEvent_t ev0[pfa::kEventRing] = {};
+  hipEvent_t ev1[pfa::kEventRing] = {};
+  uint64_t n_runs = 0;
+};
+
+namespace pfa {
+
+static uint32_t tile_sites_for(uint32_t lb, bool cds) {
+  const uint32_t ww = 64u * lb;
+  return cds ? (ww / 48u) * 48u : ww;
+}
+static uint32_t lb_for(uint32_t n_max) { return n_max <= kMaxRowsWide ? 4u : 1u; }
+
+template <int LB, bool DMA, bool CDS>
+static int launch(const pfa_plan* p, const ScanArgs& a) {
+  auto kern = scan_kernel<LB, DMA, CDS>;
+  static uint32_t lds_limit_set = 0;  // per instantiation; one process drives one device
+  if (p->lds_bytes > lds_limit_set) {
+    PFA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    lds_limit_set = p->lds_bytes;
+  }
+  dim3 grid(p->n_desc, p->n_chunks, 1), block(64, 1, 1);
+  hipLaunchKernelGGL(kern, grid, block, p->lds_bytes, ctx().stream, a);
+  PFA_HIP(hipGetLastError());
+  return PFA_OK;
+}
+
+}  // namespace pfa
+
+extern "C" {
+
+int pfa_abi_version(void) { return PFA_ABI_VERSION; }
+
+const char* pfa_last_error(void) { return pfa::g_err; }
+
+int pfa_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pfa_init(int device) {
+  pfa::Context& c = pfa::ctx();
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    pfa::set_error("no HIP device visible: libpfa_hip has no CPU fallback");
+    return PFA_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    pfa::set_error("device %d out of range (0..%d)", device, n - 1);
+    return PFA_ERR_ARG;
+  }
+  if (c.ready && c.device == device) return PFA_OK;
+  if (c.ready) pfa_shutdown();
+  PFA_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PFA_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    pfa::set_error("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    return PFA_ERR_NO_DEVICE;
+  }
+  c.n_cu = prop.multiProcessorCount;
+  c.lds_per_block = prop.sharedMemPerBlock;
+  PFA_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  c.device = device;
+  c.ready = true;
+  return PFA_OK;
+}
+
+void pfa_shutdown(void) {
+  pfa::Context& c = pfa::ctx();
+  if (!c.ready) return;
+  (void)hipStreamSynchronize(c.stream);
+  (void)hipStreamDestroy(c.stream);
+  c = pfa::Context();
+}
+
+int pfa_sync(void) {
+  PFA_NEED_INIT();
+  PFA_HIP(hipStreamSynchronize(pfa::ctx().stream));
+  return PFA_OK;
+}
+
+int pfa_dev_alloc(size_t bytes, void** out) {
+  PFA_NEED_INIT();
+  if (!out) { pfa::set_error("pfa_dev_alloc: out is NULL"); return PFA_ERR_ARG; }
+  *out = nullptr;
+  PFA_HIP(hipMalloc(out, bytes ? bytes : 16));
+  return PFA_OK;
+}
+
+int pfa_dev_free(void* p) {
+  PFA_NEED_INIT();
+  if (p) PFA_HIP(hipFree(p));
+  return PFA_OK;
+}
+
+int pfa_upload(void* dst_dev, const void* src_host, size_t bytes) {
+  PFA_NEED_INIT();
+  if (!bytes) return PFA_OK;
+  PFA_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, pfa::ctx().stream));
+  PFA_HIP(hipStreamSynchronize(pfa::ctx().stream));
+  return PFA_OK;
+}
+
+int pfa_download(void* dst_host, const void* src_dev, size_t bytes) {
+  PFA_NEED_INIT();
+  if (!bytes) return PFA_OK;
+  PFA_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, pfa::ctx().stream));
+  PFA_HIP(hipStreamSynchronize(pfa::ctx().stream));
+  return PFA_OK;
+}
+
+uint32_t pfa_tile_sites(uint32_t max_rows, uint32_t cds) {
+  return pfa::tile_sites_for(pfa::lb_for(max_rows), cds != 0);
+}
+
+uint32_t pfa_sn_words_per_tile(uint32_t max_rows) {
+  const uint32_t ncod = pfa::tile_sites_for(pfa::lb_for(max_rows), true) / 3u;
+  return 3u * ((ncod + 63u) / 64u);
+}
+
+uint32_t pfa_var_words_per_tile(uint32_t max_rows) { return pfa::lb_for(max_rows); }
+
+void pfa_plan_destroy(pfa_plan* p) {
+  if (!p) return;
+  if (pfa::ctx().ready) (void)hipStreamSynchronize(pfa::ctx().stream);
+  (void)hipFree(p->d_descs);
+  (void)hipFree(p->d_row_idx);
+  (void)hipFree(p->d_results);
+  (void)hipFree(p->d_sfs);
+  (void)hipFree(p->d_syn);
+  (void)hipFree(p->d_var_bm);
+  (void)hipFree(p->d_syn_bm);
+  (void)hipFree(p->d_non_bm);
+  for (int i = 0; i < pfa::kEventRing; ++i) {
+    if (p->ev0[i]) (void)hipEventDestroy(p->ev0[i]);
+    if (p->ev1[i]) (void)hipEventDestroy(p->ev1[i]);
+  }
+  delete p;
+}
+
+int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_idx,
+                    size_t n_row_idx, uint64_t n_bases_bytes, uint32_t want, pfa_plan** out) {
+  PFA_NEED_INIT();
+  if (!out) { pfa::set_error("pfa_plan_create: out is NULL"); return PFA_ERR_ARG; }
+  *out = nullptr;
+  if (n_desc && !descs) { pfa::set_error("pfa_plan_create: descs is NULL"); return PFA_ERR_ARG; }
+  if (n_desc == 0) { pfa::set_error("pfa_plan_create: empty descriptor table"); return PFA_ERR_ARG; }
+
+  uint32_t n_max = 0;
+  bool any_cds = false;
+  for (uint32_t i = 0; i < n_desc; ++i) {
+    n_max = std::max(n_max, descs[i].n_rows);
+    any_cds = any_cds || (descs[i].flags & PFA_FLAG_CDS);
+  }
+  if (n_max > PFA_MAX_ROWS) {
+    pfa::set_error("a scan unit has %u rows; at most %u fit one LDS column tile", n_max, PFA_MAX_ROWS);
+    return PFA_ERR_TOO_MANY_ROWS;
+  }
+  const uint32_t lb = pfa::lb_for(n_max);
+  uint64_t sfs_words = 0, tiles_total = 0;
+  uint32_t max_tiles = 0;
+  for (uint32_t i = 0; i < n_desc; ++i) {
+    const pfa_desc& d = descs[i];
+    if (d.flags & ~PFA_FLAG_CDS) {
+      pfa::set_error("desc %u: unknown flag bits 0x%x", i, d.flags);
+      return PFA_ERR_ARG;
+    }
+    const uint32_t tw = pfa::tile_sites_for(lb, d.flags & PFA_FLAG_CDS);
+    const uint32_t nt = (d.n_rows && d.n_sites) ? (uint32_t)(((uint64_t)d.n_sites + tw - 1) / tw) : 0u;
+    sfs_words = std::max<uint64_t>(sfs_words, (uint64_t)d.sfs_off + d.n_rows / 2u);
+    tiles_total = std::max<uint64_t>(tiles_total, (uint64_t)d.tile_off + nt);
+    max_tiles = std::max(max_tiles, nt);
+    if (nt == 0) continue;
+    if (d.row_stride % 16u || d.base_off % 16u) {
+      pfa::set_error("desc %u: base_off and row_stride must be multiples of 16", i);
+      return PFA_ERR_ARG;
+    }
+    if ((uint64_t)d.row_stride < (((uint64_t)d.n_sites + 15u) & ~15ull)) {
+      pfa::set_error("desc %u: row_stride %u < round_up(n_sites=%u, 16)", i, d.row_stride, d.n_sites);
+      return PFA_ERR_ARG;
+    }
+    if (d.mat_rows == 0 || (uint64_t)d.base_off + (uint64_t)d.mat_rows * d.row_stride > n_bases_bytes) {
+      pfa::set_error("desc %u: matrix [%llu, +%u x %u) exceeds the %llu-byte base buffer", i,
+                     (unsigned long long)d.base_off, d.mat_rows, d.row_stride,
+                     (unsigned long long)n_bases_bytes);
+      return PFA_ERR_ARG;
+    }
+    if (d.row_idx_off == PFA_NO_ROW_IDX) {
+      if (d.n_rows > d.mat_rows) {
+        pfa::set_error("desc %u: n_rows %u > mat_rows %u", i, d.n_rows, d.mat_rows);
+        return PFA_ERR_ARG;
+      }
+    } else {
+      if (!row_idx || (uint64_t)d.row_idx_off + d.n_rows > n_row_idx) {
+        pfa::set_error("desc %u: row_idx range out of bounds", i);
+        return PFA_ERR_ARG;
+      }
+      for (uint32_t r = 0; r < d.n_rows; ++r)
+        if (row_idx[d.row_idx_off + r] >= d.mat_rows) {
+          pfa::set_error("desc %u: row index %u >= mat_rows %u", i, row_idx[d.row_idx_off + r], d.mat_rows);
+          return PFA_ERR_ARG;
+        }
+    }
+  }
+  if (tiles_total > 0xFFFFFFFFull || sfs_words > 0xFFFFFFFFull) {
+    pfa::set_error("plan too large (tiles or SFS words overflow 32 bits)");
+    return PFA_ERR_ARG;
+  }
+
+  pfa_plan* p = new (std::nothrow) pfa_plan();
+  if (!p) { pfa::set_error("out of host memory"); return PFA_ERR_NOMEM; }
+  p->n_desc = n_desc;
+  p->lb = lb;
+  p->n_max = n_max;
+  p->any_cds = any_cds;
+  p->want = want;
+  p->sfs_words = sfs_words;
+  p->n_tiles_total = (uint32_t)tiles_total;
+  p->max_tiles = max_tiles;
+  p->n_bases_bytes = n_bases_bytes;
+  p->lds_bytes = pfa::lds_layout(lb, n_max, any_cds).total;
+
+  // chunking: enough single-wave workgroups to fill 256 CUs several times over,
+  // but whole alignments per wave once the batch is large (fewer atomics)
+  uint64_t sum_tiles = 0;
+  for (uint32_t i = 0; i < n_desc; ++i) {
+    const pfa_desc& d = descs[i];
+    const uint32_t tw = pfa::tile_sites_for(lb, d.flags & PFA_FLAG_CDS);
+    if (d.n_rows && d.n_sites) sum_tiles += ((uint64_t)d.n_sites + tw - 1) / tw;
+  }
+  const uint64_t target_blocks = (uint64_t)std::max(pfa::ctx().n_cu, 1) * 96ull;
+  uint64_t tpc = std::max<uint64_t>(1, sum_tiles / target_blocks);
+  tpc = std::min<uint64_t>(tpc, std::max<uint32_t>(max_tiles, 1));
+  tpc = std::max<uint64_t>(tpc, ((uint64_t)max_tiles + 65534ull) / 65535ull);
+  p->tiles_per_chunk = (uint32_t)tpc;
+  p->n_chunks = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)max_tiles + tpc - 1) / tpc));
+
+#define PLAN_HIP(call)                                                                        \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      pfa::set_error("%s failed: %s", #call, hipGetErrorString(e__));                         \
+      pfa_plan_destroy(p);                                                                    \
+      return PFA_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+  hipStream_t st = pfa::ctx().stream;
+  PLAN_HIP(hipMalloc((void**)&p->d_descs, (size_t)n_desc * sizeof(pfa_desc)));
+  PLAN_HIP(hipMemcpyAsync(p->d_descs, descs, (size_t)n_desc * sizeof(pfa_desc), hipMemcpyHostToDevice, st));
+  if (n_row_idx) {
+    PLAN_HIP(hipMalloc((void**)&p->d_row_idx, n_row_idx * sizeof(uint32_t)));
+    PLAN_HIP(hipMemcpyAsync(p->d_row_idx, row_idx, n_row_idx * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  }
+  PLAN_HIP(hipMalloc((void**)&p->d_results, (size_t)n_desc * sizeof(pfa_result)));
+  PLAN_HIP(hipMalloc((void**)&p->d_sfs, std::max<size_t>(16, sfs_words * sizeof(uint32_t))));
+  if (any_cds)
+    PLAN_HIP(hipMalloc((void**)&p->d_syn, (size_t)n_desc * PFA_SYN_BINS * sizeof(uint32_t)));
+  const size_t nt = std::max<size_t>(1, p->n_tiles_total);
+  if (want & PFA_WANT_VAR_BITMAP)
+    PLAN_HIP(hipMalloc((void**)&p->d_var_bm, nt * lb * sizeof(uint64_t)));
+  if ((want & PFA_WANT_SN_BITMAP) && any_cds) {
+    const size_t w = pfa_sn_words_per_tile(n_max);
+    PLAN_HIP(hipMalloc((void**)&p->d_syn_bm, nt * w * sizeof(uint64_t)));
+    PLAN_HIP(hipMalloc((void**)&p->d_non_bm, nt * w * sizeof(uint64_t)));
+    PLAN_HIP(hipMemsetAsync(p->d_syn_bm, 0, nt * w * sizeof(uint64_t), st));
+    PLAN_HIP(hipMemsetAsync(p->d_non_bm, 0, nt * w * sizeof(uint64_t), st));
+  }
+  for (int i = 0; i < pfa::kEventRing; ++i) {
+    PLAN_HIP(hipEventCreate(&p->ev0[i]));
+    PLAN_HIP(hipEventCreate(&p->ev1[i]));
+  }
+  PLAN_HIP(hipStreamSynchronize(st));
+#undef PLAN_HIP
+  *out = p;
+  return PFA_OK;
+}
+
+int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
+  PFA_NEED_INIT();
+  if (!p || !d_bases) { pfa::set_error("pfa_plan_run: NULL argument"); return PFA_ERR_ARG; }
+  hipStream_t st = pfa::ctx().stream;
+  PFA_HIP(hipMemsetAsync(p->d_results, 0, (size_t)p->n_desc * sizeof(pfa_result), st));
+  if (p->sfs_words) PFA_HIP(hipMemsetAsync(p->d_sfs, 0, p->sfs_words * sizeof(uint32_t), st));
+  if (p->d_syn) PFA_HIP(hipMemsetAsync(p->d_syn, 0, (size_t)p->n_desc * PFA_SYN_BINS * sizeof(uint32_t), st));
+
+  pfa::ScanArgs a;
+  a.bases = d_bases;
+  a.descs = p->d_descs;
+  a.row_idx = p->d_row_idx;
+  a.results = p->d_results;
+  a.sfs = p->d_sfs;
+  a.syn_num = p->d_syn;
+  a.var_bm = p->d_var_bm;
+  a.syn_bm = p->d_syn_bm;
+  a.non_bm = p->d_non_bm;
+  a.n_desc = p->n_desc;
+  a.tiles_per_chunk = p->tiles_per_chunk;
+  a.n_max = p->n_max;
+  a.pad = 0;
+
+  const int slot = (int)(p->n_runs % pfa::kEventRing);
+  PFA_HIP(hipEventRecord(p->ev0[slot], st));
+  int rc;
+  const bool dma = variant != 1;
+  if (p->lb == 4) {
+    if (p->any_cds) rc = dma ? pfa::launch<4, true, true>(p, a) : pfa::launch<4, false, true>(p, a);
+    else            rc = dma ? pfa::launch<4, true, false>(p, a) : pfa::launch<4, false, false>(p, a);
+  } else {
+    if (p->any_cds) rc = dma ? pfa::launch<1, true, true>(p, a) : pfa::launch<1, false, true>(p, a);
+    else            rc = dma ? pfa::launch<1, true, false>(p, a) : pfa::launch<1, false, false>(p, a);
+  }
+  if (rc != PFA_OK) return rc;
+  PFA_HIP(hipEventRecord(p->ev1[slot], st));
+  p->n_runs += 1;
+  return PFA_OK;
+}
+
+int pfa_plan_kernel_ms(pfa_plan* p, float* ms_out, int n) {
+  PFA_NEED_INIT();
+  if (!p || !ms_out || n < 0) { pfa::set_error("pfa_plan_kernel_ms: bad argument"); return PFA_ERR_ARG; }
+  PFA_HIP(hipStreamSynchronize(pfa::ctx().stream));
+  const uint64_t have = std::min<uint64_t>(p->n_runs, pfa::kEventRing);
+  const int cnt = (int)std::min<uint64_t>(have, (uint64_t)n);
+  for (int i = 0; i < cnt; ++i) {
+    const uint64_t run = p->n_runs - cnt + i;
+    const int slot = (int)(run % pfa::kEventRing);
+    PFA_HIP(hipEventElapsedTime(&ms_out[i], p->ev0[slot], p->ev1[slot]));
+  }
+  return cnt;
+}
+
+int pfa_plan_fetch(pfa_plan* p, pfa_result* results, uint32_t* sfs, uint32_t* syn_num,
+                   uint64_t* var_bitmap, uint64_t* syn_bitmap, uint64_t* non_bitmap) {
+  PFA_NEED_INIT();
+  if (!p) { pfa::set_error("pfa_plan_fetch: plan is NULL"); return PFA_ERR_ARG; }
+  hipStream_t st = pfa::ctx().stream;
+  const size_t nt = p->n_tiles_total;
+  if (results)
+    PFA_HIP(hipMemcpyAsync(results, p->d_results, (size_t)p->n_desc * sizeof(pfa_result), hipMemcpyDeviceToHost, st));
+  if (sfs && p->sfs_words)
+    PFA_HIP(hipMemcpyAsync(sfs, p->d_sfs, p->sfs_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  if (syn_num) {
+    if (!p->d_syn) { pfa::set_error("pfa_plan_fetch: plan has no coding unit"); return PFA_ERR_ARG; }
+    PFA_HIP(hipMemcpyAsync(syn_num, p->d_syn, (size_t)p->n_desc * PFA_SYN_BINS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  }
+  if (var_bitmap) {
+    if (!p->d_var_bm) { pfa::set_error("pfa_plan_fetch: plan was created without PFA_WANT_VAR_BITMAP"); return PFA_ERR_ARG; }
+    if (nt) PFA_HIP(hipMemcpyAsync(var_bitmap, p->d_var_bm, nt * p->lb * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  }
+  if (syn_bitmap || non_bitmap) {
+    if (!p->d_syn_bm) { pfa::set_error("pfa_plan_fetch: plan has no S/N bitmaps"); return PFA_ERR_ARG; }
+    const size_t w = pfa_sn_words_per_tile(p->n_max);
+    if (syn_bitmap && nt) PFA_HIP(hipMemcpyAsync(syn_bitmap, p->d_syn_bm, nt * w * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    if (non_bitmap && nt) PFA_HIP(hipMemcpyAsync(non_bitmap, p->d_non_bm, nt * w * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  }
+  PFA_HIP(hipStreamSynchronize(st));
+  return PFA_OK;
+}
+
+int pfa_plan_results_dev(pfa_plan* p, void** d_results, size_t* bytes) {
+  PFA_NEED_INIT();
+  if (!p || !d_results || !bytes) { pfa::set_error("pfa_plan_results_dev: NULL argument"); return PFA_ERR_ARG; }
+  *d_results = p->d_results;
+  *bytes = (size_t)p->n_desc * sizeof(pfa_result);
+  return PFA_OK;
+}
+
+uint32_t pfa_plan_n_tiles(const pfa_plan* p) { return p ? p->n_tiles_total : 0u; }
+uint64_t pfa_plan_sfs_words(const pfa_plan* p) { return p ? p->sfs_words : 0ull; }
+uint32_t pfa_plan_tiles_per_chunk(const pfa_plan* p) { return p ? p->tiles_per_chunk : 0u; }
+uint32_t pfa_plan_lds_bytes(const pfa_plan* p) { return p ? p->lds_bytes : 0u; }
+
+int pfa_scan_batch(const uint8_t* bases, uint64_t n_bases_bytes, const pfa_desc* descs,
+                   uint32_t n_desc, const uint32_t* row_idx, size_t n_row_idx,
+                   pfa_result* results, uint32_t* sfs, uint32_t* syn_num, uint64_t* var_bitmap,
+                   uint64_t* syn_bitmap, uint64_t* non_bitmap) {
+  PFA_NEED_INIT();
+  if (!bases && n_bases_bytes) { pfa::set_error("pfa_scan_batch: bases is NULL"); return PFA_ERR_ARG; }
+  pfa_plan* plan = nullptr;
+  const uint32_t want = (var_bitmap ? PFA_WANT_VAR_BITMAP : 0u) | ((syn_bitmap || non_bitmap) ? PFA_WANT_SN_BITMAP : 0u);
+  int rc = pfa_plan_create(descs, n_desc, row_idx, n_row_idx, n_bases_bytes, want, &plan);
+  if (rc != PFA_OK) return rc;
+  void* d_bases = nullptr;
+  rc = pfa_dev_alloc((size_t)n_bases_bytes, &d_bases);
+  if (rc == PFA_OK) rc = pfa_upload(d_bases, bases, (size_t)n_bases_bytes);
+  if (rc == PFA_OK) rc = pfa_plan_run(plan, (const uint8_t*)d_bases, 0);
+  if (rc == PFA_OK)
+    rc = pfa_plan_fetch(plan, results, sfs, plan->d_syn ? syn_num : nullptr, var_bitmap,
+                        plan->d_syn_bm ? syn_bitmap : nullptr, plan->d_syn_bm ? non_bitmap : nullptr);
+  if (d_bases) (void)hipFree(d_bases);
+  pfa_plan_destroy(plan);
+  return rc;
+}
+
+int64_t pfa_bitmap_positions(const uint64_t* words, uint32_t n_tiles, uint32_t words_per_tile,
+                             uint32_t tile_sites, uint32_t n_sites, uint32_t* pos_out, uint64_t cap) {
+  if (!words || (!pos_out && cap)) { pfa::set_error("pfa_bitmap_positions: NULL argument"); return PFA_ERR_ARG; }
+  // bit l of word w of a tile <-> tile-local site  per_lane * (64 * (w / per_lane) + l) + w % per_lane
+  // with per_lane = 4 or 1 (variable-site bitmap: words_per_tile = per_lane) or 3 (S/N bitmaps).
+  const uint32_t per_lane = (words_per_tile % 3u == 0u) ? 3u : words_per_tile;
+  uint64_t n = 0;
+  for (uint32_t t = 0; t < n_tiles; ++t) {
+    const uint64_t* w = words + (uint64_t)t * words_per_tile;
+    // gather in ascending site order: iterate lanes then sub-position
+    const uint32_t groups = words_per_tile / per_lane;
+    for (uint32_t g = 0; g < groups; ++g) {
+      bool any = false;
+      for (uint32_t b = 0; b < per_lane; ++b) any = any || w[g * per_lane + b];
+      if (!any) continue;
+      for (uint32_t l = 0; l < 64u; ++l)
+        for (uint32_t b = 0; b < per_lane; ++b)
+          if ((w[g * per_lane + b] >> l) & 1ull) {
+            const uint64_t site = (uint64_t)t * tile_sites + (uint64_t)per_lane * (64u * g + l) + b;
+            if (site >= n_sites) continue;
+            if (n >= cap) { pfa::set_error("pfa_bitmap_positions: output capacity %llu too small", (unsigned long long)cap); return PFA_ERR_ARG; }
+            pos_out[n++] = (uint32_t)site;
+          }
+    }
+  }
+  return (int64_t)n;
+}
+
+uint32_t pfa_classify_codon_mask(uint64_t mask) {
+  return pfa::classify_sense_mask(mask & ~pfa::kHostTables.stop_mask, pfa::kHostTables);
+}
+
+uint32_t pfa_codon_syn_thirds(uint32_t codon) { return codon < 64u ? pfa::kHostTables.syn3[codon] : 0u; }
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+"""FASTA ingest with the reference reader's record semantics
+(``readfasta``, PolyFastA.py:227-250), done by the native packer of
+libpfa_hip.so (csrc/pfa_fasta.cpp): text bytes -> row-major upper-case byte
+matrix, one byte per base, ready for upload.
+"""
+from __future__ import annotations
+
+import sys
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import FASTA_REC_DTYPE
+from .scan import row_stride_for
+
+
+@dataclass
+class Alignment:
+    """What ``readfasta`` returns as a dict, in matrix form."""
+    names: list                # headers in dict order (first occurrence)
+    seq_lens: np.ndarray       # uint32 per record
+    matrix: np.ndarray = None  # uint8 [N, L] view (row stride >= L), None when lengths differ
+    ragged: list = None        # per-record uint8 arrays when lengths differ
+
+    @property
+    def n_rows(self) -> int:
+        return len(self.names)
+
+    @property
+    def same_length(self) -> bool:
+        return bool((self.seq_lens == self.seq_lens[0]).all()) if len(self.seq_lens) else True
+
+    def to_dict(self):
+        """dict header -> sequence string, exactly what ``readfasta`` returns."""
+        rows = self.matrix if self.matrix is not None else self.ragged
+        return {n: bytes(row).decode("latin-1") for n, row in zip(self.names, rows)}
+
+
+def parse_fasta_bytes(data, stride_align: int = 16):
+    """-> Alignment, or None where the reference prints "is not FASTA" and
+    returns 1 (no header line, or the last header line is empty)."""
+    lib = _lib.load()
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    buf = np.ascontiguousarray(buf)
+    n = lib.pfa_fasta_index(_lib.ptr(buf) if len(buf) else None, len(buf), None, 0)
+    if n == _lib.PFA_ERR_FORMAT and "not FASTA" in _lib.last_error():
+        return None
+    _lib.check(n)
+    recs = np.zeros(max(n, 1), dtype=FASTA_REC_DTYPE)
+    _lib.check(lib.pfa_fasta_index(_lib.ptr(buf), len(buf), _lib.ptr(recs), n))
+    recs = recs[:n]
+    raw = buf.tobytes() if n < 4096 else None
+    names = []
+    for r in recs:
+        o, ln = int(r["name_off"]), int(r["name_len"])
+        names.append((raw[o:o + ln] if raw is not None else buf[o:o + ln].tobytes()).decode("ascii"))
+    lens = recs["seq_len"].astype(np.uint32)
+    aln = Alignment(names=names, seq_lens=lens)
+    if n and aln.same_length:
+        L = int(lens[0])
+        stride = row_stride_for(L, stride_align)
+        mat = np.empty((n, stride), dtype=np.uint8)
+        _lib.check(lib.pfa_fasta_pack(_lib.ptr(buf), len(buf), _lib.ptr(np.ascontiguousarray(recs)), n,
+                                      _lib.ptr(mat), stride))
+        aln.matrix = mat[:, :L]
+    elif n:
+        aln.ragged = []
+        for i in range(n):
+            L = int(lens[i])
+            row = np.empty(row_stride_for(L), dtype=np.uint8)
+            _lib.check(lib.pfa_fasta_pack(_lib.ptr(buf), len(buf), _lib.ptr(np.ascontiguousarray(recs[i:i + 1])), 1,
+                                          _lib.ptr(row), len(row)))
+            aln.ragged.append(row[:L])
+    return aln
+
+
+def read_fasta_file(path: str, stride_align: int = 16):
+    with open(path, "rb") as fh:
+        return parse_fasta_bytes(fh.read(), stride_align)
+
+
+def read_fasta_stdin(stride_align: int = 16):
+    return parse_fasta_bytes(sys.stdin.buffer.read(), stride_align)
+
+
+def matrix_from_dict(d, seqlen=None) -> np.ndarray:
+    """uint8 [N, seqlen] from the reference's in-memory alignment (dict header ->
+    string).  Characters must fit one byte; a sequence shorter than `seqlen`
+    is padded with NUL, which plays the role of the empty slice ``''`` that the
+    reference would see there (PolyFastA.py:256)."""
+    seqs = list(d.values())
+    if seqlen is None:
+        seqlen = len(seqs[0]) if seqs else 0
+    out = np.zeros((len(seqs), seqlen), dtype=np.uint8)
+    for i, s in enumerate(seqs):
+        try:
+            b = s[:seqlen].encode("latin-1")
+        except UnicodeEncodeError as exc:
+            raise ValueError("characters above U+00FF cannot be packed one byte per base") from exc
+        out[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+    return out

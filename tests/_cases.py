@@ -1,0 +1,57 @@
+"""Shared helpers: rebuild fixture inputs from their generator parameters."""
+import json
+import os
+
+import numpy as np
+
+from polyfasta_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name)) as fh:
+        return json.load(fh)
+
+
+def matrix_from_gen(g):
+    """uint8 [N, L] of a fixture's `gen` block (same recipe as gen_golden.gen_case)."""
+    params = synth.make_params(g["N"], g["theta"])
+    m = synth.synth_alignment(g["seed"], g["aln"], g["L"], params, coding=g.get("coding", False))
+    inj = g.get("inject")
+    if inj:
+        m = synth.inject_symbols(m, inj["seed"], inj["frac"], inj["alphabet"].encode())
+    return m
+
+
+def dict_from_gen(g):
+    return synth.to_dict(synth.headers_for(g["N"], g.get("pops", 0)), matrix_from_gen(g))
+
+
+def matrix_from_literal(d):
+    return np.array([np.frombuffer(s.encode(), dtype=np.uint8) for s in d.values()])
+
+
+def close(a, b, rel):
+    if isinstance(a, str) or isinstance(b, str):
+        return a == b
+    return a == b or abs(a - b) <= rel * max(abs(a), abs(b))
+
+
+def rows_close(got, want, rel=1e-9, rel_jc=1e-6, jc=False, abs_d=1e-9):
+    """Compare two CSV rows field by field: text equal, or numerically close.
+    Tajima's D (a cancelling difference) also passes on a small absolute gap."""
+    fa, fb = got.split(","), want.split(",")
+    assert len(fa) == len(fb), (got, want)
+    for x, y in zip(fa, fb):
+        if x == y:
+            continue
+        fx, fy = float(x), float(y)
+        tol = rel_jc if jc else rel
+        assert abs(fx - fy) <= tol * max(abs(fx), abs(fy)) or abs(fx - fy) <= abs_d, (got, want)
+    return True
+
+
+def sha1_ints(xs):
+    import hashlib
+    return hashlib.sha1(np.asarray(xs, dtype=np.int64).tobytes()).hexdigest()
