@@ -39,8 +39,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=50)
     ap.add_argument("--sites", type=int, default=10000)
     ap.add_argument("--theta", type=float, default=0.01)
-    ap.add_argument("--stride-align", type=int, default=16)
-    ap.add_argument("--variant", type=int, default=0, help="0 = LDS-DMA staging, 1 = register staging")
+    ap.add_argument("--stride-align", type=int, default=128)
+    ap.add_argument("--variant", type=int, default=0, help="0 = LDS-DMA nt (default), 1 = register staging, 2 = LDS-DMA default cache policy")
     ap.add_argument("--coding", action="store_true", help="scan as in-frame CDS (config 4 shape with --sites 9000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -125,8 +125,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         plan.run(dev, variant=args.variant)
+    t_enq = time.perf_counter() - t0
     _lib.check(lib.pfa_sync())
+    t_run = time.perf_counter() - t0
     out = plan.fetch()                       # D2H of the integer records (part of the job)
+    t_fetch = time.perf_counter() - t0 - t_run
     gathered = None
     if dist is not None:                      # the only collective: result records to every rank
         import torch
@@ -163,13 +166,15 @@ def main():
                        "rows": N, "sites": L, "batch_per_gpu": B, "row_stride": stride,
                        "parallelism": f"independent alignments sharded over {world} rank(s); one RCCL all-gather of result records"
                                       if world > 1 else "single GPU",
-                       "kernel_variant": "lds_dma" if args.variant == 0 else "register_staged",
+                       "kernel_variant": {0: "lds_dma_nt", 1: "register_staged", 2: "lds_dma_default_policy"}[args.variant],
                        "tiles_per_chunk": plan.tiles_per_chunk, "lds_bytes_per_wave": plan.lds_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "pfa::scan_kernel", "kernel_ms_avg": k_avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "frac_of_measured_copy_6290": achieved / 6290.0},
+            "timing_ms": {"enqueue": t_enq * 1e3, "until_kernels_done": t_run * 1e3, "fetch": t_fetch * 1e3,
+                          "kernel_ms_min": float(kms.min()), "kernel_ms_max": float(kms.max())},
             "check": {"mean_seg_sites": float(res["seg_sites"].mean()),
                       "sum_H": int(res["H"].sum()),
                       "gathered_records": None if gathered is None else int(len(gathered))},

@@ -135,7 +135,9 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc,
                     const uint32_t* row_idx, size_t n_row_idx,
                     uint64_t n_bases_bytes, uint32_t want, pfa_plan** out);
 /* launch on the context stream; asynchronous; returns after enqueue.
- * `variant`: 0 = default kernel, 1 = register-staged tile (A/B measurements) */
+ * `variant`: 0 = default kernel (LDS-DMA staging, non-temporal loads: the bases
+ * are read once), 1 = register-staged tile, 2 = LDS-DMA with the default cache
+ * policy (1 and 2 exist for A/B measurements) */
 int pfa_plan_run(pfa_plan* plan, const uint8_t* d_bases, int variant);
 /* elapsed milliseconds (HIP events on the launch stream) of the scan kernel of
  * the most recent `n` runs, oldest first; returns the count written or <0 */

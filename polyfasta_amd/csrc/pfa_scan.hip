@@ -82,7 +82,8 @@ PFA_HD inline LdsLayout lds_layout(uint32_t lb, uint32_t n_max, bool cds) {
   const uint32_t n = n_max ? n_max : 1u;
   LdsLayout o;
   o.tile = 0;
-  o.list = ((n + rpi - 1u) / rpi) * 1024u;
+  (void)rpi;
+  o.list = round16(n * ww);  // exactly N rows: lanes of the last DMA instruction beyond row N-1 are masked off
   o.hist = o.list + ww;
   o.rowmap = o.hist + round16((n / 2u) * 4u + 4u);
   o.hsite = o.rowmap + round16(n * 4u);
@@ -146,7 +147,7 @@ __device__ inline int codon_of(uint32_t x0, uint32_t x1, uint32_t x2) {
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int LB, bool USE_DMA, bool HAS_CDS>
+template <int LB, int STAGE, bool HAS_CDS>
 __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   using G = Geo<LB>;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -198,19 +199,24 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     {
       const uint32_t c = lane % G::LPR, rr = lane / G::LPR;
       const uint32_t col = umin(site0 + 16u * c, D.row_stride - 16u);
-      if constexpr (USE_DMA) {
+      if constexpr (STAGE != 1) {
+        // STAGE 0: default cache policy; STAGE 2: non-temporal (aux = 2), the bases are read once
         for (uint32_t g = 0; g < n_inst; ++g) {
-          const uint32_t r = umin(g * G::RPI + rr, N - 1u);
-          const uint8_t* src = mat + (uint64_t)rowmap[r] * D.row_stride + col;
-          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, 0);
+          const uint32_t r = g * G::RPI + rr;
+          if (r < N) {  // EXEC-masked lanes move nothing and leave their LDS slot untouched
+            const uint8_t* src = mat + (uint64_t)rowmap[r] * D.row_stride + col;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
+          }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
 #pragma unroll 4
         for (uint32_t g = 0; g < n_inst; ++g) {
-          const uint32_t r = umin(g * G::RPI + rr, N - 1u);
-          const uint4 v = *reinterpret_cast<const uint4*>(mat + (uint64_t)rowmap[r] * D.row_stride + col);
-          *reinterpret_cast<uint4*>(tile8 + g * 1024u + lane * 16u) = v;
+          const uint32_t r = g * G::RPI + rr;
+          if (r < N) {
+            const uint4 v = *reinterpret_cast<const uint4*>(mat + (uint64_t)rowmap[r] * D.row_stride + col);
+            *reinterpret_cast<uint4*>(tile8 + g * 1024u + lane * 16u) = v;
+          }
         }
       }
     }
@@ -471,9 +477,9 @@ static uint32_t tile_sites_for(uint32_t lb, bool cds) {
 }
 static uint32_t lb_for(uint32_t n_max) { return n_max <= kMaxRowsWide ? 4u : 1u; }
 
-template <int LB, bool DMA, bool CDS>
+template <int LB, int STAGE, bool CDS>
 static int launch(const pfa_plan* p, const ScanArgs& a) {
-  auto kern = scan_kernel<LB, DMA, CDS>;
+  auto kern = scan_kernel<LB, STAGE, CDS>;
   static uint32_t lds_limit_set = 0;  // per instantiation; one process drives one device
   if (p->lds_bytes > lds_limit_set) {
     PFA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -695,8 +701,9 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
   uint64_t tpc = std::max<uint64_t>(1, sum_tiles / target_blocks);
   tpc = std::min<uint64_t>(tpc, std::max<uint32_t>(max_tiles, 1));
   tpc = std::max<uint64_t>(tpc, ((uint64_t)max_tiles + 65534ull) / 65535ull);
-  p->tiles_per_chunk = (uint32_t)tpc;
   p->n_chunks = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)max_tiles + tpc - 1) / tpc));
+  // balance: the same number of chunks, equal shares (40 tiles in 4 chunks = 10 each, not 13+13+13+1)
+  p->tiles_per_chunk = std::max<uint32_t>(1u, (max_tiles + p->n_chunks - 1) / p->n_chunks);
 
 #define PLAN_HIP(call)                                                                        \
   do {                                                                                        \
@@ -765,14 +772,14 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   const int slot = (int)(p->n_runs % pfa::kEventRing);
   PFA_HIP(hipEventRecord(p->ev0[slot], st));
   int rc;
-  const bool dma = variant != 1;
-  if (p->lb == 4) {
-    if (p->any_cds) rc = dma ? pfa::launch<4, true, true>(p, a) : pfa::launch<4, false, true>(p, a);
-    else            rc = dma ? pfa::launch<4, true, false>(p, a) : pfa::launch<4, false, false>(p, a);
-  } else {
-    if (p->any_cds) rc = dma ? pfa::launch<1, true, true>(p, a) : pfa::launch<1, false, true>(p, a);
-    else            rc = dma ? pfa::launch<1, true, false>(p, a) : pfa::launch<1, false, false>(p, a);
-  }
+  // kernel STAGE: 2 = LDS-DMA non-temporal (default), 1 = register staging, 0 = LDS-DMA default cache policy
+  const int stage = variant == 1 ? 1 : variant == 2 ? 0 : 2;
+#define PFA_LAUNCH(LB, CDS)                                            \
+  (stage == 0 ? pfa::launch<LB, 0, CDS>(p, a)                          \
+              : stage == 1 ? pfa::launch<LB, 1, CDS>(p, a) : pfa::launch<LB, 2, CDS>(p, a))
+  if (p->lb == 4) rc = p->any_cds ? PFA_LAUNCH(4, true) : PFA_LAUNCH(4, false);
+  else            rc = p->any_cds ? PFA_LAUNCH(1, true) : PFA_LAUNCH(1, false);
+#undef PFA_LAUNCH
   if (rc != PFA_OK) return rc;
   PFA_HIP(hipEventRecord(p->ev1[slot], st));
   p->n_runs += 1;

@@ -1,0 +1,182 @@
+"""Host-side logic and the C-ABI surface, without a GPU: the library loads and
+exports every symbol include/pfa.h declares, struct layouts match, the FASTA
+packer / host generator / codon classifier / finishing math agree with the
+golden vectors, and compute entry points fail loudly when no device exists."""
+import ctypes
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+
+from polyfasta_amd import _lib, api, cli, fasta, scan, stats, synth
+from tests import _cases as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "pfa.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(pfa_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in pfa.h but not exported"
+    assert declared == set(_lib._PROTOTYPES), declared ^ set(_lib._PROTOTYPES)
+    assert lib.pfa_abi_version() == _lib.PFA_ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    assert _lib.DESC_DTYPE.itemsize == 40 and _lib.DESC_DTYPE.fields["mat_rows"][1] == 36
+    assert _lib.RESULT_DTYPE.itemsize == 56 and _lib.RESULT_DTYPE.fields["seg_sites"][1] == 24
+    assert _lib.FASTA_REC_DTYPE.itemsize == 32
+    assert ctypes.sizeof(_lib.SynthParamsC) == 48
+
+
+def test_no_cpu_fallback_without_device():
+    lib = _lib.load()
+    if lib.pfa_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    assert lib.pfa_init(0) == -1 and "no CPU fallback" in _lib.last_error()
+    with pytest.raises(_lib.PfaError):
+        scan.scan_matrix(np.full((3, 16), 65, dtype=np.uint8))
+    with pytest.raises(_lib.PfaError):
+        api.getvarsites({"a": "ACGT", "b": "ACGA"}, 4)
+    p = ctypes.c_void_p()
+    assert lib.pfa_dev_alloc(16, ctypes.byref(p)) == -2      # PFA_ERR_NOT_INIT
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "polyfasta_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "oracle" not in text.replace("no oracle", ""), f"{fn} mentions the oracle"
+
+
+def test_fasta_packer_matches_reference_reader():
+    for name, rec in C.load("g3_fasta_syntax.json").items():
+        aln = fasta.parse_fasta_bytes(rec["text"].encode())
+        if rec["records"] is None:
+            assert aln is None, name
+            continue
+        assert [[h, s] for h, s in aln.to_dict().items()] == rec["records"], name
+        assert aln.same_length == rec["same_length"], name
+    with pytest.raises(_lib.PfaError):
+        fasta.parse_fasta_bytes(">a\nAC\xc3\x9fT\n".encode("latin-1"))
+
+
+def test_fasta_packer_on_examples_and_wrapped_text():
+    for fn in sorted(os.listdir(f"{C.GOLDEN}/example_theta_0.01")):
+        if not fn.endswith(".fa"):
+            continue
+        aln = fasta.read_fasta_file(f"{C.GOLDEN}/example_theta_0.01/{fn}")
+        assert aln.matrix.shape == (20, 1000) and aln.names[0] == "indiv1"
+        text = synth.to_fasta_text(aln.names, aln.matrix, wrap=60, newline="\r\n")
+        again = fasta.parse_fasta_bytes(text.encode())
+        assert again.names == aln.names and (again.matrix == aln.matrix).all()
+        assert aln.matrix.strides[0] % 16 == 0
+
+
+def test_host_generator_matches_numpy_spec():
+    lib = _lib.load()
+    for N, L, theta, cod in ((50, 1000, 0.01, 0), (7, 333, 0.2, 1), (1, 10, 0.1, 0), (2, 17, 0.5, 1), (300, 257, 0.05, 0)):
+        p = synth.make_params(N, theta)
+        stride = scan.row_stride_for(L)
+        sp = _lib.SynthParamsC(seed=9, first_aln=5, n_aln=3, n_rows=N, n_sites=L, row_stride=stride,
+                               seg_thresh=p.seg_thresh, tri_thresh=p.tri_thresh, n_units=len(p.units), coding=cod)
+        out = np.zeros(3 * N * stride, dtype=np.uint8)
+        cdf, units = np.ascontiguousarray(p.cdf), np.ascontiguousarray(p.units)
+        _lib.check(lib.pfa_synth_fill_host(_lib.ptr(out), ctypes.byref(sp), _lib.ptr(cdf) if len(cdf) else None, _lib.ptr(units)))
+        for m in range(3):
+            want = synth.synth_alignment(9, 5 + m, L, p, coding=bool(cod))
+            assert (out[m * N * stride:(m + 1) * N * stride].reshape(N, stride)[:, :L] == want).all()
+
+
+def test_codon_classifier_matches_reference_tables():
+    """The host entry point runs the same code as the device path (pfa_codon.h)."""
+    g4 = C.load("g4_codon_sets.json")
+    sense = g4["sense"]
+
+    def code(cods):
+        s, n = api.get_syn_nonsyn_cod_sites([cods, 0])
+        return sum(1 << p for p in s) | sum(8 << p for p in n)
+
+    for pair, want in zip(itertools.combinations(sense, 2), g4["pairs"]):
+        assert code(list(pair)) == want
+    for tri, want in zip(itertools.combinations(sense, 3), bytes.fromhex(g4["triples"])):
+        assert code(list(tri)) == want
+    for cs, want in g4["sets"]:
+        assert code([cs[i:i + 3] for i in range(0, len(cs), 3)]) == want
+    for c, t in g4["syn_thirds"].items():
+        assert round(api.syncodfreq(c) * 3) == t
+    assert api.get_syn_nonsyn_cod_sites([["ATG", "NNN", "A-G"], 9]) == ([], [])
+    with pytest.raises(KeyError):
+        api.syncodfreq("ANA")
+
+
+def test_finishing_math_from_integers():
+    """stats.finish_polymorphism(S, H, N, L, jc) against the reference's floats."""
+    n = 0
+    for rec in C.load("g2_synthetic.json") + list(C.load("g1_examples.json").values()):
+        for jc, key in ((False, "poly"), (True, "poly_jc")):
+            got = stats.finish_polymorphism(rec["S"], rec["H"], rec["N"], rec["L"], jc)
+            want = rec[key]
+            assert got[0] == want[0] and type(got[1]) is type(want[1])
+            assert C.close(got[1], want[1], 1e-6 if jc else 1e-9) and C.close(got[2], want[2], 1e-9)
+            assert C.close(got[3], want[3], 1e-9) or abs(got[3] - want[3]) < 1e-9
+            n += 1
+    assert n > 800
+    assert stats.finish_polymorphism(0, 0, 5, 100, True) == (0, 0, 0, "NA")
+    assert stats.finish_polymorphism(3, 4, 2, 10, False)[3] == "NA"       # N = 2: zero variance term
+    assert stats.finish_polymorphism(1, 2 * 4 * 4, 5, 1, True)[1] == stats.pi_total(32, 5)   # JC argument >= 0.75 falls back
+
+
+def test_bitmap_expansion():
+    lib = _lib.load()
+    words = np.zeros(8, dtype=np.uint64)
+    words[0] = 1 | (1 << 63)          # tile 0, word 0: sites 0 and 252
+    words[3] = 2                      # tile 0, word 3: site 4*1+3 = 7
+    words[5] = 1 << 2                 # tile 1, word 1: site 256 + 4*2+1 = 265
+    out = np.zeros(16, dtype=np.uint32)
+    n = lib.pfa_bitmap_positions(_lib.ptr(words), 2, 4, 256, 300, _lib.ptr(out), 16)
+    assert out[:n].tolist() == [0, 7, 252, 265]
+    assert lib.pfa_bitmap_positions(_lib.ptr(words), 2, 4, 256, 260, _lib.ptr(out), 16) == 3   # site >= n_sites dropped
+    assert lib.pfa_bitmap_positions(_lib.ptr(words), 2, 4, 256, 300, _lib.ptr(out), 2) < 0
+    sn = np.zeros(6, dtype=np.uint64)
+    sn[2] = 1                         # group 0, p = 2, lane 0 -> site 2
+    sn[3] = 1 << 15                   # group 1, p = 0, lane 15 -> site 3*(64+15) = 237
+    n = lib.pfa_bitmap_positions(_lib.ptr(sn), 1, 6, 240, 240, _lib.ptr(out), 16)
+    assert out[:n].tolist() == [2, 237]
+
+
+def test_batch_packing_and_layout():
+    b = scan.Batch(stride_align=128)
+    m1 = np.full((5, 1000), 65, dtype=np.uint8)
+    m2 = np.full((7, 30), 67, dtype=np.uint8)
+    i1, i2 = b.add_matrix(m1), b.add_matrix(m2)
+    b.add_unit(i1)
+    b.add_unit(i2, rows=[0, 6, 3], cds=True)
+    b.add_unit(i1, cds=True)
+    bases, t = b.pack()
+    d = t.descs
+    assert d["row_stride"].tolist() == [1024, 128, 1024] and (d["base_off"] % 256 == 0).all()
+    assert d["n_rows"].tolist() == [5, 3, 5] and d["sfs_off"].tolist() == [0, 2, 3]
+    assert t.n_tiles.tolist() == [4, 1, 5] and d["tile_off"].tolist() == [0, 4, 5]
+    assert t.row_idx.tolist() == [0, 6, 3] and d["row_idx_off"].tolist() == [_lib.PFA_NO_ROW_IDX, 0, _lib.PFA_NO_ROW_IDX]
+    assert (bases[int(d["base_off"][1]):int(d["base_off"][1]) + 30] == 67).all()
+
+
+def test_row_formatting_matches_reference_rows():
+    res = np.zeros(1, dtype=_lib.RESULT_DTYPE)[0]
+    assert cli.format_plain_row("f.fa", "NA", 3, 8, res, False) == "f.fa,8,NA,3,0,0,0,NA"
+    syn = np.zeros(65, dtype=np.uint32)
+    syn[1] = 4
+    assert cli.format_cds_row("novar.fa", "NA", 2, 9, res, syn, False) == "novar.fa,1.33,7.67,NA,2,0,0,0,NA,0,0,0,NA,0"
+    g1 = C.load("g1_examples.json")["file1.fa"]
+    res["seg_sites"], res["H"] = g1["S"], g1["H"]
+    row = cli.format_plain_row("file1.fa", "NA", 20, 1000, res, False)
+    C.rows_close(row, "file1.fa,1000,NA,20,87,0.01410000000000001,0.024522656228401073,-1.7406412034629681")

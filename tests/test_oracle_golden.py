@@ -1,0 +1,126 @@
+"""Pin the CPU oracle (Python restatement and C restatement) to the golden
+vectors frozen from the reference (tests/golden/, made by gen_golden.py).
+No GPU and no reference needed."""
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import polyfasta_oracle as orc
+from tests import _cases as C
+
+REL = 1e-11
+
+
+def _check_py(rec, d, L):
+    pos, var = orc.getvarsites(d, L)
+    assert len(var) == rec["S"] and pos[:24] == rec["pos_head"] and C.sha1_ints(pos) == rec["pos_sha1"]
+    summ = orc.integer_summary(d, L)
+    assert summ["H"] == rec["H"]
+    if rec["S"]:
+        assert (summ["sfs"] if summ["sfs"] is not None else "IndexError") == rec["sfs"]
+    for jc, key in ((False, "poly"), (True, "poly_jc")):
+        got = orc.polymorphism(var, L, jc)
+        assert got[0] == rec[key][0] and all(C.close(x, y, REL) for x, y in zip(got[1:], rec[key][1:]))
+
+
+def _check_c(rec, m, cds=False):
+    o = c_oracle.scan(m, cds=cds, want_sites=True)
+    assert (o["S"], o["H"]) == (rec["S"], rec["H"])
+    assert C.sha1_ints(np.flatnonzero(o["h_site"])) == rec["pos_sha1"]
+    if rec["S"]:
+        if rec["sfs"] == "IndexError":
+            assert o["sfs_bad"] > 0
+        else:
+            assert o["sfs_bad"] == 0 and o["sfs"].tolist() == rec["sfs"]
+    if cds:
+        c = rec["cds"]
+        assert np.flatnonzero(o["labels"] == 1).tolist() == c["S_pos"]
+        assert np.flatnonzero(o["labels"] == 2).tolist() == c["N_pos"]
+        assert (o["nstops"], 3 * o["missing_cols"]) == (c["nstops"], c["missing"])
+        assert C.close(o["count_syn"], c["count_syn"], 1e-12)
+
+
+def test_examples_g1():
+    for fn, rec in C.load("g1_examples.json").items():
+        d = orc.readfasta(f"{C.GOLDEN}/example_theta_0.01/{fn}")
+        _check_py(rec, d, rec["L"])
+        _check_c(rec, C.matrix_from_literal(d), cds=True)
+        for jc, key in ((False, "row"), (True, "row_jc")):
+            C.rows_close(orc.result_row(d, rec["L"], True, "x.fa", "NA", jc), rec["cds"][key], rel=1e-10, rel_jc=1e-10)
+
+
+def test_synthetic_grid_g2():
+    for rec in C.load("g2_synthetic.json"):
+        m = C.matrix_from_gen(rec["gen"])
+        _check_c(rec, m)
+        if rec["N"] * rec["L"] <= 300_000:      # pure-Python loops: small cases only
+            _check_py(rec, C.dict_from_gen(rec["gen"]), rec["L"])
+
+
+def test_fasta_syntax_g3(tmp_path):
+    for name, rec in C.load("g3_fasta_syntax.json").items():
+        p = tmp_path / f"{name}.fa"
+        p.write_bytes(rec["text"].encode())
+        d = orc.readfasta(str(p))
+        if rec["records"] is None:
+            assert d is None
+            continue
+        assert [[h, s] for h, s in d.items()] == rec["records"]
+        if rec.get("same_length"):
+            L = len(rec["records"][0][1])
+            _check_py(rec, d, L)
+            C.rows_close(orc.result_row(d, L, False, name, "NA", False), rec["row"], rel=1e-12)
+
+
+def test_codon_sets_g4():
+    g4 = C.load("g4_codon_sets.json")
+    sense = g4["sense"]
+    assert sense == list(orc.SENSE_CODONS)
+
+    def code(cods):
+        s, n = orc.get_syn_nonsyn_cod_sites([cods, 0])
+        return sum(1 << p for p in s) | sum(8 << p for p in n)
+
+    for pair, want in zip(itertools.combinations(sense, 2), g4["pairs"]):
+        assert code(list(pair)) == want == code(list(pair)[::-1])
+    for tri, want in zip(itertools.combinations(sense, 3), bytes.fromhex(g4["triples"])):
+        assert code(list(tri)) == want
+    for cs, want in g4["sets"]:
+        assert code([cs[i:i + 3] for i in range(0, len(cs), 3)]) == want
+    for c, t in g4["syn_thirds"].items():
+        assert orc.syn_thirds(c) == t
+
+
+def test_coding_g5():
+    for rec in C.load("g5_cds.json"):
+        if "gen" in rec:
+            d, m = C.dict_from_gen(rec["gen"]), C.matrix_from_gen(rec["gen"])
+        else:
+            d, m = rec["literal"], C.matrix_from_literal(rec["literal"])
+        L = rec["L"]
+        _check_c(rec, m, cds=True)
+        cs, s, n, nstops, missing = orc.getvarCDSsites(d, L)
+        c = rec["cds"]
+        assert C.close(cs, c["count_syn"], 1e-12) and sorted(s) == c["S_pos"] and sorted(n) == c["N_pos"]
+        assert (nstops, missing) == (c["nstops"], c["missing"])
+        for jc, key in ((False, "row"), (True, "row_jc")):
+            C.rows_close(orc.result_row(d, L, True, "x.fa", "NA", jc), c[key], rel=1e-10, rel_jc=1e-10)
+
+
+def test_pops_g6():
+    from polyfasta_amd import synth
+    for case in C.load("g6_pops.json"):
+        d = C.dict_from_gen(case["gen"])
+        if case["extra_gen"]:
+            for i, (_, s) in enumerate(C.dict_from_gen(case["extra_gen"]).items()):
+                d[f"pop10_x{i}"] = s
+        for key, want in case["rows"].items():
+            if want is None:
+                assert orc.split_pop(d, key) == {}
+                continue
+            pop, cds, jc = key.split("|")
+            grp = orc.split_pop(d, pop)
+            got = orc.result_row(grp, case["gen"]["L"], cds == "cds=1", "x.fa", pop, jc == "jc=1")
+            C.rows_close(got, want, rel=1e-10, rel_jc=1e-10)
