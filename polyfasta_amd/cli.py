@@ -111,20 +111,98 @@ def build_parser():
     return p
 
 
-def _flush(batch, pending, sink, cds, jc):
-    """Scan the batch and emit the pending events in order."""
+def _scan_pending(batch, pending, done):
+    """Scan the batch; move the pending events, units now carrying their integer
+    record and coding bins, to `done`."""
     out = scan_batch(batch) if batch.n_units else None
     for ev in pending:
-        if ev[0] == "comment":
-            sink.comment(ev[1])
-        elif ev[0] == "stdout":
-            print(ev[1])
+        if ev[1] == "unit":
+            fidx, _, unit, name, pop, n_rows, seqlen = ev
+            syn = out.syn_num[unit].copy() if out.syn_num is not None else None
+            done.append((fidx, "unit", name, pop, n_rows, seqlen, out.results[unit].copy(), syn))
         else:
-            _, unit, name, pop, n_rows, seqlen = ev
-            res = out.results[unit]
-            text = (format_cds_row(name, pop, n_rows, seqlen, res, out.syn_num[unit], jc) if cds
+            done.append(ev)
+
+
+def process_files(indexed_paths, args):
+    """Parse, pack and scan the given (index, path) pairs in batches; returns
+    the ordered output events of these files (PolyFastA.py:104-140)."""
+    batch, pending, done = Batch(stride_align=128), [], []
+    for fidx, path in indexed_paths:
+        aln = fasta.read_fasta_stdin() if args.pipe else fasta.read_fasta_file(path)
+        if aln is None:
+            pending.append((fidx, "stdout", f"# file {path} is not FASTA!"))        # :247 (always stdout)
+            continue
+        name = path.split("/")[-1]                                                 # :110
+        if not aln.same_length:
+            pending.append((fidx, "comment", f"# Sequences do not have the same length: {name}"))   # :135-140
+            continue
+        seqlen = int(aln.seq_lens[0])
+        if args.cds and seqlen % 3 != 0:                                           # :114-119
+            pending.append((fidx, "comment", f"# CDS sequence length is not a multiple of 3: {name}"))
+        mid = batch.add_matrix(aln.matrix)
+        if not args.pops:                                                          # :120-121
+            unit = batch.add_unit(mid, cds=args.cds)
+            pending.append((fidx, "unit", unit, name, "NA", aln.n_rows, seqlen))
+        else:
+            for pop in args.pops.split(","):                                       # :123-134
+                rows = [i for i, h in enumerate(aln.names) if pop in h]
+                if len(rows) == 0:
+                    pending.append((fidx, "comment", f"# Pop {pop} string was not found in fasta headers."))
+                    continue
+                unit = batch.add_unit(mid, rows=np.asarray(rows, dtype=np.uint32), cds=args.cds)
+                pending.append((fidx, "unit", unit, name, pop, len(rows), seqlen))
+        if batch.nbytes >= BATCH_BYTES:
+            _scan_pending(batch, pending, done)
+            batch, pending = Batch(stride_align=128), []
+    _scan_pending(batch, pending, done)
+    return done
+
+
+def emit(events, sink, cds, jc):
+    """Finish the floats and write the rows / comment lines in order."""
+    for ev in events:
+        if ev[1] == "comment":
+            sink.comment(ev[2])
+        elif ev[1] == "stdout":
+            print(ev[2])
+        else:
+            _, _, name, pop, n_rows, seqlen, res, syn = ev
+            text = (format_cds_row(name, pop, n_rows, seqlen, res, syn, jc) if cds
                     else format_plain_row(name, pop, n_rows, seqlen, res, jc))
             sink.row(text, name, pop)
+
+
+def gather_events(group, events):
+    """Multi-GPU: the integer records travel through ONE all-gather of fixed-size
+    structs (RCCL on the GPU box); the small text metadata through gather_object.
+    Returns the merged, file-ordered event list on rank 0 (None elsewhere)."""
+    from ._lib import PFA_SYN_BINS, RESULT_DTYPE
+    units = [ev for ev in events if ev[1] == "unit"]
+    rec = np.zeros(len(units), dtype=RESULT_DTYPE)
+    syn = np.zeros((len(units), PFA_SYN_BINS), dtype=np.uint32)
+    for i, ev in enumerate(units):
+        rec[i] = ev[6]
+        if ev[7] is not None:
+            syn[i] = ev[7]
+    all_rec = group.all_gather_records(rec)
+    all_syn = group.all_gather_records(syn.reshape(-1))
+    meta = [ev[:6] if ev[1] == "unit" else ev for ev in events]      # no numpy payload
+    all_meta = group.gather_objects(meta, dst=0)
+    if group.rank != 0:
+        return None
+    merged = []
+    for r in range(group.world):
+        k = 0
+        syn_r = all_syn[r].reshape(-1, PFA_SYN_BINS)
+        for seq, ev in enumerate(all_meta[r]):
+            if ev[1] == "unit":
+                merged.append((ev[0], r, seq, ev + (all_rec[r][k], syn_r[k])))
+                k += 1
+            else:
+                merged.append((ev[0], r, seq, ev))
+    merged.sort(key=lambda t: (t[0], t[1], t[2]))
+    return [t[3] for t in merged]
 
 
 def main(argv=None):
@@ -142,43 +220,29 @@ def main(argv=None):
         args.file = [args.dir + "/" + i for i in os.listdir(args.dir)]
     elif len(args.file) == 0 and args.dir == "." and args.pipe:                    # :96-100
         args.file = ["stdin"] if not args.name else [args.name]
+    if len(args.file) > 0 and args.pipe and not (args.file[0] == "stdin" or args.file[0] == args.name):
+        parser.error("A FASTA file or multiple files cannot be used with the --pipe argument.")   # :105-106
+
+    from .dist import Group, env_world, shard_indices
+    rank, _, world = env_world()
+    group = Group() if world > 1 else None
 
     sink = Sink(args.out, args.silent)
-    sink.header(args.cds)                                                          # :102-103
-
-    batch, pending = Batch(), []
-    for path in sorted(args.file):                                                 # :104
-        if len(args.file) > 0 and args.pipe and not (args.file[0] == "stdin" or args.file[0] == args.name):
-            parser.error("A FASTA file or multiple files cannot be used with the --pipe argument.")
-        aln = fasta.read_fasta_stdin() if args.pipe else fasta.read_fasta_file(path)
-        if aln is None:
-            pending.append(("stdout", f"# file {path} is not FASTA!"))              # :247 (always stdout)
-            continue
-        name = path.split("/")[-1]                                                 # :110
-        if not aln.same_length:
-            pending.append(("comment", f"# Sequences do not have the same length: {name}"))   # :135-140
-            continue
-        seqlen = int(aln.seq_lens[0])
-        if args.cds and seqlen % 3 != 0:                                           # :114-119
-            pending.append(("comment", f"# CDS sequence length is not a multiple of 3: {name}"))
-        mid = batch.add_matrix(aln.matrix)
-        if not args.pops:                                                          # :120-121
-            unit = batch.add_unit(mid, cds=args.cds)
-            pending.append(("unit", unit, name, "NA", aln.n_rows, seqlen))
-        else:
-            for pop in args.pops.split(","):                                       # :123-134
-                rows = [i for i, h in enumerate(aln.names) if pop in h]
-                if len(rows) == 0:
-                    pending.append(("comment", f"# Pop {pop} string was not found in fasta headers."))
-                    continue
-                unit = batch.add_unit(mid, rows=np.asarray(rows, dtype=np.uint32), cds=args.cds)
-                pending.append(("unit", unit, name, pop, len(rows), seqlen))
-        if batch.nbytes >= BATCH_BYTES:
-            _flush(batch, pending, sink, args.cds, args.jc)
-            batch, pending = Batch(), []
-    _flush(batch, pending, sink, args.cds, args.jc)
-    if len(args.out) != 0 and not args.silent:                                     # :141-142
-        print("")
+    if rank == 0:
+        sink.header(args.cds)                                                      # :102-103
+    paths = sorted(args.file)                                                      # :104
+    mine = [(i, paths[i]) for i in shard_indices(len(paths), rank, world)] if not args.pipe else \
+        ([(0, paths[0])] if rank == 0 and paths else [])
+    events = process_files(mine, args)
+    if group is not None:
+        events = gather_events(group, events)
+        group.barrier()
+    if rank == 0:
+        emit(events, sink, args.cds, args.jc)
+        if len(args.out) != 0 and not args.silent:                                 # :141-142
+            print("")
+    if group is not None:
+        group.close()
     return 0
 
 

@@ -458,6 +458,11 @@ struct pfa_plan {
   uint32_t lds_bytes = 0;
   pfa_desc* d_descs = nullptr;
   uint32_t* d_row_idx = nullptr;
+  // results | sfs | syn_num live in ONE device slab (one memset per run) mirrored
+  // by one pinned host slab (one D2H per fetch)
+  uint8_t* d_slab = nullptr;
+  uint8_t* h_slab = nullptr;
+  size_t slab_bytes = 0, off_sfs = 0, off_syn = 0;
   pfa_result* d_results = nullptr;
   uint32_t* d_sfs = nullptr;
   uint32_t* d_syn = nullptr;
@@ -594,9 +599,8 @@ void pfa_plan_destroy(pfa_plan* p) {
   if (pfa::ctx().ready) (void)hipStreamSynchronize(pfa::ctx().stream);
   (void)hipFree(p->d_descs);
   (void)hipFree(p->d_row_idx);
-  (void)hipFree(p->d_results);
-  (void)hipFree(p->d_sfs);
-  (void)hipFree(p->d_syn);
+  (void)hipFree(p->d_slab);
+  if (p->h_slab) (void)hipHostFree(p->h_slab);
   (void)hipFree(p->d_var_bm);
   (void)hipFree(p->d_syn_bm);
   (void)hipFree(p->d_non_bm);
@@ -722,10 +726,17 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
     PLAN_HIP(hipMalloc((void**)&p->d_row_idx, n_row_idx * sizeof(uint32_t)));
     PLAN_HIP(hipMemcpyAsync(p->d_row_idx, row_idx, n_row_idx * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   }
-  PLAN_HIP(hipMalloc((void**)&p->d_results, (size_t)n_desc * sizeof(pfa_result)));
-  PLAN_HIP(hipMalloc((void**)&p->d_sfs, std::max<size_t>(16, sfs_words * sizeof(uint32_t))));
-  if (any_cds)
-    PLAN_HIP(hipMalloc((void**)&p->d_syn, (size_t)n_desc * PFA_SYN_BINS * sizeof(uint32_t)));
+  {
+    auto up = [](size_t x) { return (x + 255u) & ~size_t(255); };
+    p->off_sfs = up((size_t)n_desc * sizeof(pfa_result));
+    p->off_syn = p->off_sfs + up(std::max<size_t>(16, sfs_words * sizeof(uint32_t)));
+    p->slab_bytes = p->off_syn + (any_cds ? up((size_t)n_desc * PFA_SYN_BINS * sizeof(uint32_t)) : 0);
+    PLAN_HIP(hipMalloc((void**)&p->d_slab, p->slab_bytes));
+    PLAN_HIP(hipHostMalloc((void**)&p->h_slab, p->slab_bytes, hipHostMallocDefault));
+    p->d_results = reinterpret_cast<pfa_result*>(p->d_slab);
+    p->d_sfs = reinterpret_cast<uint32_t*>(p->d_slab + p->off_sfs);
+    p->d_syn = any_cds ? reinterpret_cast<uint32_t*>(p->d_slab + p->off_syn) : nullptr;
+  }
   const size_t nt = std::max<size_t>(1, p->n_tiles_total);
   if (want & PFA_WANT_VAR_BITMAP)
     PLAN_HIP(hipMalloc((void**)&p->d_var_bm, nt * lb * sizeof(uint64_t)));
@@ -750,9 +761,7 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   PFA_NEED_INIT();
   if (!p || !d_bases) { pfa::set_error("pfa_plan_run: NULL argument"); return PFA_ERR_ARG; }
   hipStream_t st = pfa::ctx().stream;
-  PFA_HIP(hipMemsetAsync(p->d_results, 0, (size_t)p->n_desc * sizeof(pfa_result), st));
-  if (p->sfs_words) PFA_HIP(hipMemsetAsync(p->d_sfs, 0, p->sfs_words * sizeof(uint32_t), st));
-  if (p->d_syn) PFA_HIP(hipMemsetAsync(p->d_syn, 0, (size_t)p->n_desc * PFA_SYN_BINS * sizeof(uint32_t), st));
+  PFA_HIP(hipMemsetAsync(p->d_slab, 0, p->slab_bytes, st));
 
   pfa::ScanArgs a;
   a.bases = d_bases;
@@ -806,13 +815,14 @@ int pfa_plan_fetch(pfa_plan* p, pfa_result* results, uint32_t* sfs, uint32_t* sy
   if (!p) { pfa::set_error("pfa_plan_fetch: plan is NULL"); return PFA_ERR_ARG; }
   hipStream_t st = pfa::ctx().stream;
   const size_t nt = p->n_tiles_total;
-  if (results)
-    PFA_HIP(hipMemcpyAsync(results, p->d_results, (size_t)p->n_desc * sizeof(pfa_result), hipMemcpyDeviceToHost, st));
-  if (sfs && p->sfs_words)
-    PFA_HIP(hipMemcpyAsync(sfs, p->d_sfs, p->sfs_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  if (syn_num) {
-    if (!p->d_syn) { pfa::set_error("pfa_plan_fetch: plan has no coding unit"); return PFA_ERR_ARG; }
-    PFA_HIP(hipMemcpyAsync(syn_num, p->d_syn, (size_t)p->n_desc * PFA_SYN_BINS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  if (syn_num && !p->d_syn) { pfa::set_error("pfa_plan_fetch: plan has no coding unit"); return PFA_ERR_ARG; }
+  if (results || sfs || syn_num) {
+    // one D2H into pinned memory, then plain memcpy into the caller's (pageable) arrays
+    PFA_HIP(hipMemcpyAsync(p->h_slab, p->d_slab, p->slab_bytes, hipMemcpyDeviceToHost, st));
+    PFA_HIP(hipStreamSynchronize(st));
+    if (results) memcpy(results, p->h_slab, (size_t)p->n_desc * sizeof(pfa_result));
+    if (sfs && p->sfs_words) memcpy(sfs, p->h_slab + p->off_sfs, p->sfs_words * sizeof(uint32_t));
+    if (syn_num) memcpy(syn_num, p->h_slab + p->off_syn, (size_t)p->n_desc * PFA_SYN_BINS * sizeof(uint32_t));
   }
   if (var_bitmap) {
     if (!p->d_var_bm) { pfa::set_error("pfa_plan_fetch: plan was created without PFA_WANT_VAR_BITMAP"); return PFA_ERR_ARG; }
