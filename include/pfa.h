@@ -219,6 +219,38 @@ int64_t pfa_fasta_index(const uint8_t* text, uint64_t n_text, pfa_fasta_rec* rec
 int pfa_fasta_pack(const uint8_t* text, uint64_t n_text, const pfa_fasta_rec* recs, uint64_t n_recs,
                    uint8_t* bases_out, uint32_t row_stride);
 
+
+/* Batch loader: read, index and pack `n_files` FASTA files with `n_threads`
+ * host threads (0 = 16) into `bases_out` (capacity `cap` bytes); matrices are
+ * 256-byte aligned, placed in arbitrary order (info[i].base_off), row stride =
+ * round_up(n_sites, stride_align).  info[i].status: 0 = packed,
+ * PFA_FILE_NOT_FASTA, PFA_FILE_UNEQUAL (sequences of different lengths; the
+ * reference prints a comment line for both, PolyFastA.py:135-140,246-248),
+ * PFA_FILE_DEFERRED = did not fit this call's buffer (submit it again; when it
+ * is larger than `cap`, row_stride holds the needed bytes / 256), PFA_ERR_IO =
+ * unreadable.  names_out (optional): the record names of file i, each
+ * NUL-terminated, back to back from info[i].names_off (--pops matching). */
+#define PFA_FILE_NOT_FASTA 1
+#define PFA_FILE_UNEQUAL 2
+#define PFA_FILE_DEFERRED 3
+typedef struct pfa_file_info {
+  int32_t status;
+  uint32_t n_rows;
+  uint32_t n_sites;
+  uint32_t row_stride;
+  uint64_t base_off;  /* into bases_out */
+  uint64_t names_off; /* into names_out */
+} pfa_file_info;
+int pfa_fasta_load_files(const char* const* paths, uint32_t n_files, uint32_t stride_align,
+                         uint32_t n_threads, uint8_t* bases_out, uint64_t cap, pfa_file_info* info,
+                         char* names_out, uint64_t names_cap, uint64_t* bytes_used,
+                         uint64_t* names_used);
+
+/* pinned (page-locked) host memory for the ingest buffer: pre-faulted, and H2D
+ * from it runs at the PCIe rate */
+int pfa_host_alloc(size_t bytes, void** out);
+int pfa_host_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,15 @@ FASTA_REC_DTYPE = np.dtype([
     ("name_off", "<u8"), ("name_len", "<u4"), ("seq_len", "<u4"),
     ("first_line_off", "<u8"), ("end_off", "<u8"),
 ], align=True)
+FILE_INFO_DTYPE = np.dtype([
+    ("status", "<i4"), ("n_rows", "<u4"), ("n_sites", "<u4"), ("row_stride", "<u4"),
+    ("base_off", "<u8"), ("names_off", "<u8"),
+], align=True)
+PFA_FILE_NOT_FASTA = 1
+PFA_FILE_UNEQUAL = 2
+PFA_FILE_DEFERRED = 3
+PFA_ERR_IO = -8
+assert FILE_INFO_DTYPE.itemsize == 32
 assert DESC_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 56 and FASTA_REC_DTYPE.itemsize == 32
 
 
@@ -99,6 +108,10 @@ _PROTOTYPES = {
     "pfa_synth_fill_host": (ctypes.c_int, [_vp, ctypes.POINTER(SynthParamsC), _vp, _vp]),
     "pfa_fasta_index": (ctypes.c_int64, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint64]),
     "pfa_fasta_pack": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint64, _vp, ctypes.c_uint32]),
+    "pfa_fasta_load_files": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp,
+                                            ctypes.c_uint64, _vp, _vp, ctypes.c_uint64, u64p, u64p]),
+    "pfa_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "pfa_host_free": (ctypes.c_int, [_vp]),
 }
 
 _lib = None

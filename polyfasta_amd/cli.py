@@ -21,15 +21,31 @@ import sys
 import numpy as np
 
 from . import fasta, stats
-from .scan import Batch, scan_batch
+from ._lib import (DESC_DTYPE, PFA_ERR_IO, PFA_FILE_DEFERRED, PFA_FILE_NOT_FASTA, PFA_FILE_UNEQUAL,
+                   PFA_FLAG_CDS, PFA_NO_ROW_IDX)
+from .scan import Batch, DeviceBuffer, Plan, finalize_layout, scan_batch
 
 HEADER_PLAIN = "file,seqlen,pop,N,seg_sites,pi,theta,tajimasD"
 HEADER_CDS = ("file,sites_S,sites_N,pop,N,seg_sites_S,seg_sites_N,pi_S,pi_N,theta_S,theta_N,"
               "tajimasD_S,tajimasD_N,nstops")
 NO_VAR = "0,0,0,NA"
 
-# batches are cut when the packed bases exceed this many bytes
-BATCH_BYTES = 1 << 30
+# ingest buffer (pinned host memory, allocated once per process) and files per loader call
+BATCH_BYTES = 512 << 20
+FILES_PER_CALL = 8192
+_pinned_cache = None
+
+
+def _ingest_buffer(min_bytes=0):
+    """The process-wide pinned ingest buffer (hipHostMalloc costs ~60 ms per GB, so
+    it is sized once and reused by every batch)."""
+    global _pinned_cache
+    want = max(BATCH_BYTES, int(min_bytes))
+    if _pinned_cache is None or len(_pinned_cache.array) < want:
+        if _pinned_cache is not None:
+            _pinned_cache.free()
+        _pinned_cache = fasta.PinnedBuffer(want)
+    return _pinned_cache
 
 
 def format_plain_row(name, pop, n_rows, seqlen, res, jc):
@@ -111,10 +127,45 @@ def build_parser():
     return p
 
 
-def _scan_pending(batch, pending, done):
-    """Scan the batch; move the pending events, units now carrying their integer
-    record and coding bins, to `done`."""
-    out = scan_batch(batch) if batch.n_units else None
+def _scan_table(bases, used, descs, row_idx):
+    """Upload the packed bases, scan every unit, return the ScanOutput."""
+    table = finalize_layout(descs, row_idx, used)
+    dev = DeviceBuffer(max(used, 16))
+    try:
+        dev.upload(bases[:used])
+        plan = Plan(table)
+        try:
+            plan.run(dev)
+            return plan.fetch()
+        finally:
+            plan.close()
+    finally:
+        dev.free()
+
+
+def _events_for(fidx, path, name, status, names, n_rows, seqlen, args, add_unit):
+    """Output events of one parsed file (PolyFastA.py:107-140); `add_unit(rows)`
+    registers a scan unit and returns its index."""
+    evs = []
+    if status == PFA_FILE_NOT_FASTA:
+        return [(fidx, "stdout", f"# file {path} is not FASTA!")]                   # :247 (always stdout)
+    if status == PFA_FILE_UNEQUAL:
+        return [(fidx, "comment", f"# Sequences do not have the same length: {name}")]   # :135-140
+    if args.cds and seqlen % 3 != 0:                                               # :114-119
+        evs.append((fidx, "comment", f"# CDS sequence length is not a multiple of 3: {name}"))
+    if not args.pops:                                                              # :120-121
+        evs.append((fidx, "unit", add_unit(None), name, "NA", n_rows, seqlen))
+    else:
+        for pop in args.pops.split(","):                                           # :123-134
+            rows = [i for i, h in enumerate(names) if pop in h]
+            if len(rows) == 0:
+                evs.append((fidx, "comment", f"# Pop {pop} string was not found in fasta headers."))
+                continue
+            evs.append((fidx, "unit", add_unit(rows), name, pop, len(rows), seqlen))
+    return evs
+
+
+def _attach(pending, out, done):
     for ev in pending:
         if ev[1] == "unit":
             fidx, _, unit, name, pop, n_rows, seqlen = ev
@@ -125,37 +176,80 @@ def _scan_pending(batch, pending, done):
 
 
 def process_files(indexed_paths, args):
-    """Parse, pack and scan the given (index, path) pairs in batches; returns
-    the ordered output events of these files (PolyFastA.py:104-140)."""
-    batch, pending, done = Batch(stride_align=128), [], []
-    for fidx, path in indexed_paths:
-        aln = fasta.read_fasta_stdin() if args.pipe else fasta.read_fasta_file(path)
-        if aln is None:
-            pending.append((fidx, "stdout", f"# file {path} is not FASTA!"))        # :247 (always stdout)
-            continue
-        name = path.split("/")[-1]                                                 # :110
-        if not aln.same_length:
-            pending.append((fidx, "comment", f"# Sequences do not have the same length: {name}"))   # :135-140
-            continue
-        seqlen = int(aln.seq_lens[0])
-        if args.cds and seqlen % 3 != 0:                                           # :114-119
-            pending.append((fidx, "comment", f"# CDS sequence length is not a multiple of 3: {name}"))
-        mid = batch.add_matrix(aln.matrix)
-        if not args.pops:                                                          # :120-121
-            unit = batch.add_unit(mid, cds=args.cds)
-            pending.append((fidx, "unit", unit, name, "NA", aln.n_rows, seqlen))
-        else:
-            for pop in args.pops.split(","):                                       # :123-134
-                rows = [i for i, h in enumerate(aln.names) if pop in h]
-                if len(rows) == 0:
-                    pending.append((fidx, "comment", f"# Pop {pop} string was not found in fasta headers."))
+    """Ingest (native multi-threaded packer), scan (one launch per batch) and
+    return the ordered output events of the given (index, path) pairs
+    (PolyFastA.py:104-140)."""
+    done = []
+    if args.pipe:
+        for fidx, path in indexed_paths:
+            aln = fasta.read_fasta_stdin(stride_align=128)
+            status = PFA_FILE_NOT_FASTA if aln is None else (0 if aln.same_length else PFA_FILE_UNEQUAL)
+            batch = Batch(stride_align=128)
+            mid = batch.add_matrix(aln.matrix) if status == 0 else None
+            pending = _events_for(fidx, path, path.split("/")[-1], status, aln.names if aln else None,
+                                  aln.n_rows if aln else 0, int(aln.seq_lens[0]) if status == 0 else 0, args,
+                                  lambda rows: batch.add_unit(mid, rows=None if rows is None else np.asarray(rows, dtype=np.uint32), cds=args.cds))
+            _attach(pending, scan_batch(batch) if batch.n_units else None, done)
+        return done
+
+    todo = list(indexed_paths)
+    pinned = _ingest_buffer()
+    while todo:
+        chunk, todo = todo[:FILES_PER_CALL], todo[FILES_PER_CALL:]
+        bases = pinned.array
+        info, names, used = fasta.load_files([p for _, p in chunk], bases, stride_align=128,
+                                             want_names=bool(args.pops))
+        status = info["status"]
+        if (status == PFA_ERR_IO).any():
+            path = chunk[int(np.flatnonzero(status == PFA_ERR_IO)[0])][1]
+            open(path, "rb").close()          # raises the OSError the reference would raise (:239)
+            raise OSError(f"cannot read {path}")
+        deferred = [chunk[k] for k in np.flatnonzero(status == PFA_FILE_DEFERRED)]
+        descs, ridx, pending = [], None, []
+        if not args.pops:
+            # one unit per packed file: build the descriptor table without a Python loop
+            ok = np.flatnonzero(status == 0)
+            descs = np.zeros(len(ok), dtype=DESC_DTYPE)
+            for f in ("base_off", "n_sites", "row_stride"):
+                descs[f] = info[f][ok]
+            descs["n_rows"] = descs["mat_rows"] = info["n_rows"][ok]
+            descs["row_idx_off"] = PFA_NO_ROW_IDX
+            descs["flags"] = PFA_FLAG_CDS if args.cds else 0
+            unit_of = dict(zip(ok.tolist(), range(len(ok))))
+            for k, fi in enumerate(info.tolist()):
+                st = fi[0]
+                if st == PFA_FILE_DEFERRED:
                     continue
-                unit = batch.add_unit(mid, rows=np.asarray(rows, dtype=np.uint32), cds=args.cds)
-                pending.append((fidx, "unit", unit, name, pop, len(rows), seqlen))
-        if batch.nbytes >= BATCH_BYTES:
-            _scan_pending(batch, pending, done)
-            batch, pending = Batch(stride_align=128), []
-    _scan_pending(batch, pending, done)
+                fidx, path = chunk[k]
+                pending += _events_for(fidx, path, path.split("/")[-1], st, None, fi[1], fi[2], args,
+                                       lambda rows, k=k: unit_of[k])
+        else:
+            dl, rl = [], []
+            for k, fi in enumerate(info):
+                st = int(fi["status"])
+                if st == PFA_FILE_DEFERRED:
+                    continue
+                fidx, path = chunk[k]
+
+                def add_unit(rows, fi=fi):
+                    d = np.zeros(1, dtype=DESC_DTYPE)[0]
+                    d["base_off"], d["n_sites"], d["row_stride"], d["mat_rows"] = fi["base_off"], fi["n_sites"], fi["row_stride"], fi["n_rows"]
+                    d["flags"] = PFA_FLAG_CDS if args.cds else 0
+                    d["n_rows"], d["row_idx_off"] = len(rows), sum(len(r) for r in rl)
+                    rl.append(np.asarray(rows, dtype=np.uint32))
+                    dl.append(d)
+                    return len(dl) - 1
+                pending += _events_for(fidx, path, path.split("/")[-1], st, names[k], int(fi["n_rows"]),
+                                       int(fi["n_sites"]), args, add_unit)
+            descs = np.array(dl, dtype=DESC_DTYPE) if dl else []
+            ridx = np.concatenate(rl) if rl else None
+        if len(deferred) == len(chunk):
+            # nothing fitted: the first file alone is larger than the buffer -> grow it
+            pinned = _ingest_buffer((int(info[0]["row_stride"]) << 8) + (1 << 20))
+        out = _scan_table(bases, used, descs, ridx) if len(descs) else None
+        _attach(pending, out, done)
+        todo = deferred + todo
+    done.sort(key=lambda ev: ev[0])       # stable: deferred files return to their sorted position
     return done
 
 

@@ -15,8 +15,14 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <stdio.h>
+
+#include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -25,6 +31,7 @@
 namespace pfa {
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 }
+static std::string pfa_last_error_local() { return std::string(pfa_last_error()); }
 
 namespace {
 
@@ -37,11 +44,25 @@ struct Line {
 };
 
 inline Line next_line(const uint8_t* t, uint64_t n, uint64_t pos) {
-  uint64_t e = pos;
-  while (e < n && t[e] != '\n' && t[e] != '\r') ++e;
+  // memchr for '\n', then look for an earlier '\r' inside that span (CRLF or a lone CR)
+  const uint8_t* nl = static_cast<const uint8_t*>(memchr(t + pos, '\n', n - pos));
+  uint64_t e = nl ? uint64_t(nl - t) : n;
+  const uint8_t* cr = static_cast<const uint8_t*>(memchr(t + pos, '\r', e - pos));
+  if (cr) e = uint64_t(cr - t);
   uint64_t nx = e;
   if (nx < n) nx += (t[nx] == '\r' && nx + 1 < n && t[nx + 1] == '\n') ? 2 : 1;
   return Line{pos, e, nx};
+}
+
+// upper-case copy; returns the OR of all bytes (bit 7 set <=> a non-ASCII byte was seen)
+inline uint8_t copy_upper(uint8_t* dst, const uint8_t* src, uint64_t n) {
+  uint8_t acc = 0;
+  for (uint64_t k = 0; k < n; ++k) {
+    const uint8_t c = src[k];
+    acc |= c;
+    dst[k] = uint8_t(c - ((uint8_t(c - 'a') < 26u) << 5));
+  }
+  return acc;
 }
 
 inline uint64_t rstrip_end(const uint8_t* t, uint64_t b, uint64_t e) {
@@ -89,9 +110,7 @@ int64_t pfa_fasta_index(const uint8_t* text, uint64_t n_text, pfa_fasta_rec* rec
       have_head = true;
       head_named = !name.empty();
     } else if (head_named) {
-      const uint64_t e = rstrip_end(text, ln.begin, ln.end);
-      for (uint64_t i = ln.begin; i < e; ++i)
-        if (text[i] >= 0x80) { pfa::set_error("non-ASCII byte 0x%02x in a sequence line at offset %llu", text[i], (unsigned long long)i); return PFA_ERR_FORMAT; }
+      const uint64_t e = rstrip_end(text, ln.begin, ln.end);   // (bytes >= 0x80 are rejected by the pack pass)
       const uint64_t add = e - ln.begin;
       if ((uint64_t)out[cur].seq_len + add > 0xFFFFFFFFull) { pfa::set_error("sequence longer than 2^32-1"); return PFA_ERR_FORMAT; }
       out[cur].seq_len += (uint32_t)add;
@@ -128,15 +147,118 @@ int pfa_fasta_pack(const uint8_t* text, uint64_t n_text, const pfa_fasta_rec* re
       const Line ln = next_line(text, r.end_off, pos);
       const uint64_t e = rstrip_end(text, ln.begin, ln.end);
       if (w + (e - ln.begin) > r.seq_len) { pfa::set_error("pfa_fasta_pack: record %llu longer than indexed", (unsigned long long)i); return PFA_ERR_ARG; }
-      for (uint64_t k = ln.begin; k < e; ++k) {
-        const uint8_t c = text[k];
-        row[w++] = (c >= 'a' && c <= 'z') ? uint8_t(c - 32) : c;
+      if (copy_upper(row + w, text + ln.begin, e - ln.begin) & 0x80u) {
+        pfa::set_error("non-ASCII byte in a sequence line of record %llu (one byte per base only)", (unsigned long long)i);
+        return PFA_ERR_FORMAT;
       }
+      w += e - ln.begin;
       pos = ln.next;
     }
     if (w != r.seq_len) { pfa::set_error("pfa_fasta_pack: record %llu shorter than indexed", (unsigned long long)i); return PFA_ERR_ARG; }
     if (row_stride > w) memset(row + w, 0, row_stride - w);
   }
+  return PFA_OK;
+}
+
+
+// ---- multi-threaded batch loader ---------------------------------------------
+// Reads, indexes and packs many FASTA files with a pool of host threads: what
+// limits alignments/s end to end is this ingest, not the scan.
+// One pass per file (read -> index -> reserve -> pack) with thread-local,
+// reused text buffers; matrices are bump-allocated in `bases_out`, so their
+// order in the buffer is arbitrary (descriptors carry the offsets).
+int pfa_fasta_load_files(const char* const* paths, uint32_t n_files, uint32_t stride_align, uint32_t n_threads,
+                         uint8_t* bases_out, uint64_t cap, pfa_file_info* info, char* names_out,
+                         uint64_t names_cap, uint64_t* bytes_used, uint64_t* names_used) {
+  if (!paths || !bases_out || !info || !bytes_used) { pfa::set_error("pfa_fasta_load_files: NULL argument"); return PFA_ERR_ARG; }
+  if (stride_align < 16 || (stride_align & (stride_align - 1))) { pfa::set_error("stride_align must be a power of two >= 16"); return PFA_ERR_ARG; }
+  const uint32_t nt = std::max(1u, std::min<uint32_t>(n_threads ? n_threads : 16u, std::max(1u, n_files)));
+  std::atomic<uint32_t> next{0};
+  std::atomic<uint64_t> used{0}, nused{0};
+  std::atomic<int> hard_rc{0};
+  std::string hard_msg;
+  std::mutex msg_mu;
+
+  auto reserve = [](std::atomic<uint64_t>& ctr, uint64_t need, uint64_t limit, uint64_t* off) {
+    uint64_t cur = ctr.load();
+    do {
+      if (cur + need > limit) return false;
+    } while (!ctr.compare_exchange_weak(cur, cur + need));
+    *off = cur;
+    return true;
+  };
+
+  auto worker = [&]() {
+    std::vector<uint8_t> text;
+    std::vector<pfa_fasta_rec> recs;
+    for (;;) {
+      const uint32_t i = next.fetch_add(1);
+      if (i >= n_files) break;
+      pfa_file_info& fi = info[i];
+      memset(&fi, 0, sizeof(fi));
+      FILE* fh = fopen(paths[i], "rb");
+      if (!fh) { fi.status = PFA_ERR_IO; continue; }
+      fseek(fh, 0, SEEK_END);
+      const long sz = ftell(fh);
+      fseek(fh, 0, SEEK_SET);
+      if (sz < 0) { fclose(fh); fi.status = PFA_ERR_IO; continue; }
+      if (text.size() < (size_t)sz) text.resize((size_t)sz);
+      const size_t got = sz > 0 ? fread(text.data(), 1, (size_t)sz, fh) : 0;
+      fclose(fh);
+      if (got != (size_t)sz) { fi.status = PFA_ERR_IO; continue; }
+      int64_t n = pfa_fasta_index(text.data(), (uint64_t)sz, nullptr, 0);
+      if (n == PFA_ERR_FORMAT) { fi.status = PFA_FILE_NOT_FASTA; continue; }
+      if (n >= 0) {
+        recs.resize((size_t)n);
+        n = pfa_fasta_index(text.data(), (uint64_t)sz, recs.data(), (uint64_t)n);
+      }
+      if (n < 0) {
+        std::lock_guard<std::mutex> g(msg_mu);
+        hard_rc = (int)n;
+        hard_msg = std::string(paths[i]) + ": " + pfa_last_error_local();
+        continue;
+      }
+      fi.n_rows = (uint32_t)n;
+      fi.n_sites = n ? recs[0].seq_len : 0;
+      for (auto& r : recs)
+        if (r.seq_len != fi.n_sites) { fi.status = PFA_FILE_UNEQUAL; break; }
+      uint64_t st = 0, need = 0, nneed = 0;
+      if (fi.status == 0) {
+        st = std::max<uint64_t>(16, ((uint64_t)fi.n_sites + stride_align - 1) & ~uint64_t(stride_align - 1));
+        if (st > 0xFFFFFFF0ull) { fi.status = PFA_FILE_UNEQUAL; continue; }
+        fi.row_stride = (uint32_t)st;
+        need = (((uint64_t)std::max(fi.n_rows, 1u) * st) + 255u) & ~255ull;
+      }
+      if (names_out)
+        for (auto& r : recs) nneed += r.name_len + 1u;
+      uint64_t off = 0, noff = 0;
+      if (need && !reserve(used, need, cap, &off)) { fi.status = PFA_FILE_DEFERRED; fi.row_stride = (uint32_t)std::min<uint64_t>(need >> 8, 0xFFFFFFFFull); continue; }
+      if (nneed && !reserve(nused, nneed, names_cap, &noff)) { fi.status = PFA_FILE_DEFERRED; continue; }
+      fi.base_off = off;
+      fi.names_off = noff;
+      if (names_out) {
+        char* q = names_out + noff;
+        for (auto& r : recs) { memcpy(q, text.data() + r.name_off, r.name_len); q[r.name_len] = 0; q += r.name_len + 1u; }
+      }
+      if (fi.status == 0 && fi.n_rows) {
+        const int rc = pfa_fasta_pack(text.data(), (uint64_t)sz, recs.data(), recs.size(), bases_out + off, fi.row_stride);
+        if (rc != PFA_OK) {
+          std::lock_guard<std::mutex> g(msg_mu);
+          hard_rc = rc;
+          hard_msg = std::string(paths[i]) + ": " + pfa_last_error_local();
+        }
+      }
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < nt; ++t) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+  }
+  if (hard_rc != 0) { pfa::set_error("%s", hard_msg.c_str()); return hard_rc; }
+  *bytes_used = used.load();
+  if (names_used) *names_used = nused.load();
   return PFA_OK;
 }
 

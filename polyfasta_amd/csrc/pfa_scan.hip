@@ -567,6 +567,20 @@ int pfa_dev_free(void* p) {
   return PFA_OK;
 }
 
+int pfa_host_alloc(size_t bytes, void** out) {
+  PFA_NEED_INIT();
+  if (!out) { pfa::set_error("pfa_host_alloc: out is NULL"); return PFA_ERR_ARG; }
+  *out = nullptr;
+  PFA_HIP(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+  return PFA_OK;
+}
+
+int pfa_host_free(void* p) {
+  PFA_NEED_INIT();
+  if (p) PFA_HIP(hipHostFree(p));
+  return PFA_OK;
+}
+
 int pfa_upload(void* dst_dev, const void* src_host, size_t bytes) {
   PFA_NEED_INIT();
   if (!bytes) return PFA_OK;

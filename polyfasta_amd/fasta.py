@@ -75,6 +75,61 @@ def parse_fasta_bytes(data, stride_align: int = 16):
     return aln
 
 
+def load_files(paths, bases_out: np.ndarray, stride_align: int = 128, want_names: bool = False, threads: int = 0):
+    """Native multi-threaded ingest of many files into `bases_out` (uint8 buffer).
+    Returns (info FILE_INFO_DTYPE[len(paths)], names or None, bytes_used).
+    info.status == PFA_FILE_DEFERRED marks files that did not fit this call's
+    buffer.  `names[i]` is the list of record names of file i (want_names)."""
+    import ctypes
+    import os
+    lib = _lib.load()
+    n = len(paths)
+    arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    info = np.zeros(n, dtype=_lib.FILE_INFO_DTYPE)
+    names_buf = np.zeros(64 * 1024 * 1024 if want_names else 1, dtype=np.uint8)
+    used, nused = ctypes.c_uint64(), ctypes.c_uint64()
+    threads = threads or int(os.environ.get("PFA_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    _lib.check(lib.pfa_fasta_load_files(arr, n, stride_align, threads, _lib.ptr(bases_out), bases_out.nbytes,
+                                        _lib.ptr(info), _lib.ptr(names_buf) if want_names else None, names_buf.nbytes,
+                                        ctypes.byref(used), ctypes.byref(nused)))
+    names = None
+    if want_names:
+        raw = names_buf[:nused.value].tobytes()
+        names = []
+        for fi in info:
+            k = int(fi["n_rows"])
+            if k == 0 or int(fi["status"]) == _lib.PFA_FILE_DEFERRED:
+                names.append([])
+                continue
+            o = int(fi["names_off"])
+            names.append([p.decode("ascii") for p in raw[o:].split(b"\0", k)[:k]])
+    return info, names, used.value
+
+
+class PinnedBuffer:
+    """Page-locked host buffer (hipHostMalloc) exposed as a numpy uint8 array."""
+
+    def __init__(self, nbytes: int):
+        import ctypes
+        _lib.init()
+        p = ctypes.c_void_p()
+        _lib.check(_lib.load().pfa_host_alloc(int(nbytes), ctypes.byref(p)))
+        self.ptr = p
+        self.array = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(int(nbytes),))
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            self.array = None
+            _lib.load().pfa_host_free(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def read_fasta_file(path: str, stride_align: int = 16):
     with open(path, "rb") as fh:
         return parse_fasta_bytes(fh.read(), stride_align)
