@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--stride-align", type=int, default=128)
     ap.add_argument("--variant", type=int, default=0, help="0 = LDS-DMA nt (default), 1 = register staging, 2 = LDS-DMA default cache policy")
     ap.add_argument("--coding", action="store_true", help="scan as in-frame CDS (config 4 shape with --sites 9000)")
+    ap.add_argument("--pops", type=int, default=0,
+                    help="config 3 shape: every matrix holds rows*pops sequences, scanned as `pops` interleaved row subsets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -94,21 +96,29 @@ def main():
     _lib.init(local_rank)
 
     N, L, B = args.rows, args.sites, args.batch
-    params = synth.make_params(N, args.theta)
+    K = max(args.pops, 1)
+    NM = N * K                               # rows of each matrix
+    params = synth.make_params(NM, args.theta)
     stride = scan.row_stride_for(L, args.stride_align)
-    nbytes = B * N * stride
+    nbytes = B * NM * stride
     dev = scan.DeviceBuffer(nbytes)
-    sp = _lib.SynthParamsC(seed=2026, first_aln=rank * B, n_aln=B, n_rows=N, n_sites=L, row_stride=stride,
+    sp = _lib.SynthParamsC(seed=2026, first_aln=rank * B, n_aln=B, n_rows=NM, n_sites=L, row_stride=stride,
                            seg_thresh=params.seg_thresh, tri_thresh=params.tri_thresh, n_units=len(params.units),
                            coding=int(args.coding))
     _lib.check(lib.pfa_synth_fill_dev(dev.ptr, ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(params.cdf)),
                                       _lib.ptr(np.ascontiguousarray(params.units))))
-    descs = np.zeros(B, dtype=_lib.DESC_DTYPE)
-    descs["base_off"] = np.arange(B, dtype=np.uint64) * np.uint64(N * stride)
-    descs["n_rows"], descs["n_sites"], descs["row_stride"], descs["mat_rows"] = N, L, stride, N
+    descs = np.zeros(B * K, dtype=_lib.DESC_DTYPE)
+    descs["base_off"] = np.repeat(np.arange(B, dtype=np.uint64) * np.uint64(NM * stride), K)
+    descs["n_rows"], descs["n_sites"], descs["row_stride"], descs["mat_rows"] = N, L, stride, NM
     descs["row_idx_off"] = _lib.PFA_NO_ROW_IDX
     descs["flags"] = _lib.PFA_FLAG_CDS if args.coding else 0
-    table = scan.finalize_layout(descs, None, nbytes)
+    if os.environ.get("PFA_BENCH_MIX_ONE_CDS"):   # experiment: coding-capable kernel on non-coding units
+        descs["flags"][0] = _lib.PFA_FLAG_CDS
+    row_idx = None
+    if args.pops:                            # population k = rows k, k+K, k+2K, ... (headers pop{1+i%K}_ind{i})
+        row_idx = np.concatenate([np.arange(k, NM, K, dtype=np.uint32) for k in range(K)])
+        descs["row_idx_off"] = np.tile(np.arange(K, dtype=np.uint32) * N, B)
+    table = scan.finalize_layout(descs, row_idx, nbytes)
     plan = scan.Plan(table)
 
     def sync_all():
@@ -149,12 +159,12 @@ def main():
 
     kms = plan.kernel_ms(args.steps)
     k_avg_ms = float(kms.mean()) if len(kms) else float("nan")
-    alg_bytes = float(B) * N * L
+    alg_bytes = float(B) * NM * L           # every base of every population is read once
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
 
     if rank == 0:
         res = out.results
-        total_aln = world * B * args.steps
+        total_aln = world * B * K * args.steps   # scan units (alignment x population) = CSV rows
         line = {
             "metric": "alignments/sec", "value": total_aln / dt, "unit": "alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -163,7 +173,8 @@ def main():
             "site_columns_per_sec": total_aln * L / dt,
             "config": {"workload": f"BASELINE configs[1] shape as a device-resident batch: {B} distinct alignments "
                                    f"per GPU per step, N={N} x L={L}, theta={args.theta}, "
-                                   f"{'coding (--cds)' if args.coding else 'non-coding'}",
+                                   f"{'coding (--cds)' if args.coding else 'non-coding'}"
+                                   + (f", {K} populations of {N} rows per matrix" if args.pops else ""),
                        "rows": N, "sites": L, "batch_per_gpu": B, "row_stride": stride,
                        "parallelism": f"independent alignments sharded over {world} rank(s); one RCCL all-gather of result records"
                                       if world > 1 else "single GPU",
@@ -180,7 +191,7 @@ def main():
                       "sum_H": int(res["H"].sum()),
                       "gathered_records": None if gathered is None else int(len(gathered))},
         }
-        if world == 1 and not args.no_cpu_baseline and not args.coding:
+        if world == 1 and not args.no_cpu_baseline and not args.coding and not args.pops:
             cb, (s_cpu, h_cpu) = cpu_baseline(args, params)
             line["cpu_baseline"] = cb
             # the CPU sample is the first 128 alignments of rank 0's batch: integers must agree

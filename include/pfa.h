@@ -59,11 +59,10 @@ extern "C" {
 #define PFA_WANT_VAR_BITMAP 1u /* variable-site bitmap  -> `pos` of getvarsites        */
 #define PFA_WANT_SN_BITMAP 2u  /* S / N position bitmaps -> lists of getvarCDSsites    */
 
-/* Column-tile widths (sites per wavefront tile) for plans whose largest unit has
- * at most 600 rows; above that the tile narrows to 64 / 48 sites so that N rows
- * still fit LDS.  Query with pfa_tile_sites().  Bitmaps are laid out per tile. */
-#define PFA_TILE_SITES 256u     /* non-coding units                                    */
-#define PFA_TILE_SITES_CDS 240u /* coding units: 80 whole codons, 16-byte aligned start */
+/* Column-tile width (sites per wavefront tile) for plans whose largest unit has
+ * at most 600 rows; above that the tile narrows to 64 sites so that N rows still
+ * fit LDS.  Query with pfa_tile_sites().  Bitmaps are laid out per tile. */
+#define PFA_TILE_SITES 256u
 
 /* One scan unit = one alignment, or one population's row subset of an
  * alignment (PolyFastA.py:122-134).  `bases` holds row-major matrices, ONE
@@ -107,12 +106,11 @@ typedef struct pfa_result {
 typedef struct pfa_plan pfa_plan;
 
 /* tile geometry of a plan whose largest unit has `max_rows` rows: sites per
- * tile (coding / non-coding units), 64-bit words per tile of the variable-site
- * bitmap and of each S / N bitmap.  tile_off of unit i = sum over earlier units
- * of ceil(n_sites / pfa_tile_sites(max_rows, unit is coding)). */
+ * tile (the same for coding and non-coding units; `cds` is ignored) and 64-bit
+ * words per tile of every bitmap.  tile_off of unit i = sum over earlier units
+ * of ceil(n_sites / pfa_tile_sites(max_rows, 0)). */
 uint32_t pfa_tile_sites(uint32_t max_rows, uint32_t cds);
 uint32_t pfa_var_words_per_tile(uint32_t max_rows);
-uint32_t pfa_sn_words_per_tile(uint32_t max_rows);
 
 /* ---- context -------------------------------------------------------------- */
 int pfa_abi_version(void);
@@ -144,8 +142,7 @@ int pfa_plan_run(pfa_plan* plan, const uint8_t* d_bases, int variant);
 int pfa_plan_kernel_ms(pfa_plan* plan, float* ms_out, int n);
 /* synchronise and copy outputs to host; any pointer may be NULL.
  * sizes: results[n_desc], sfs[sfs_words], syn_num[n_desc*PFA_SYN_BINS],
- *        var_bitmap[n_tiles * pfa_var_words_per_tile()], syn/non_bitmap[n_tiles *
- *        pfa_sn_words_per_tile()] uint64 (tile-interleaved, below) */
+ *        every bitmap: n_tiles * pfa_var_words_per_tile() uint64 (tile-interleaved, below) */
 int pfa_plan_fetch(pfa_plan* plan, pfa_result* results, uint32_t* sfs, uint32_t* syn_num,
                    uint64_t* var_bitmap, uint64_t* syn_bitmap, uint64_t* non_bitmap);
 /* device pointer of the result records (n_desc x pfa_result), e.g. to hand to
@@ -164,11 +161,10 @@ int pfa_scan_batch(const uint8_t* bases, uint64_t n_bases_bytes,
                    pfa_result* results, uint32_t* sfs, uint32_t* syn_num,
                    uint64_t* var_bitmap, uint64_t* syn_bitmap, uint64_t* non_bitmap);
 
-/* Bitmap layout ("tile-interleaved", the order the wavefront ballots produce).
- * var_bitmap: W = pfa_var_words_per_tile() words per tile (4, or 1 for narrow
- * tiles); bit l of word b of tile t <-> site t*TILE + W*l + b.  syn/non bitmaps:
- * 3*G words per tile (coding units only; G = 2 for 240-site tiles, 1 for 48);
- * bit l of word 3*g + p <-> site t*TILE + 3*(64*g + l) + p.
+/* Bitmap layout ("tile-interleaved", the order the wavefront ballots produce),
+ * the same for the variable-site, synonymous and non-synonymous bitmaps:
+ * W = pfa_var_words_per_tile() words per tile (4, or 1 for narrow tiles); bit l
+ * of word b of tile t <-> site t*TILE + W*l + b.
  * pfa_bitmap_positions() expands one unit's words to ascending positions;
  * returns the count, or <0 if `cap` is too small. */
 int64_t pfa_bitmap_positions(const uint64_t* words, uint32_t n_tiles, uint32_t words_per_tile,

@@ -86,7 +86,6 @@ _PROTOTYPES = {
     "pfa_download": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     "pfa_tile_sites": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_uint32]),
     "pfa_var_words_per_tile": (ctypes.c_uint32, [ctypes.c_uint32]),
-    "pfa_sn_words_per_tile": (ctypes.c_uint32, [ctypes.c_uint32]),
     "pfa_plan_create": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp, ctypes.c_size_t, ctypes.c_uint64,
                                        ctypes.c_uint32, ctypes.POINTER(_vp)]),
     "pfa_plan_run": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),

@@ -155,7 +155,8 @@ constexpr uint8_t pair_rule(int c1, int c2) {
 
 struct Tables {
   uint8_t pair[64 * 64];  // pair_rule(c1, c2)
-  uint8_t annot_id[64];   // dense id of the annotation label (equal labels <=> equal ids); 255 for stops
+  uint8_t annot_id[64];   // dense id (< 32) of the annotation label (equal labels <=> equal ids); 255 for stops
+  uint8_t annot_info[64]; // id | 0x20 if the label is L4N or L2R | 0x40 if R4N or R2R; 255 for stops
   uint8_t syn3[64];       // syn_thirds
   uint64_t stop_mask;
   uint64_t t_mask[5];     // t_mask[v]: codons whose syn_thirds == v (v = 1..4)
@@ -179,6 +180,12 @@ constexpr Tables make_tables() {
       if (!is_stop(d) && annot(d) == annot(c)) { id = t.annot_id[d]; break; }
     t.annot_id[c] = uint8_t(id >= 0 ? id : next++);
   }
+  for (int c = 0; c < 64; ++c) {
+    if (is_stop(c)) { t.annot_info[c] = 255; continue; }
+    const uint32_t a = annot(c);
+    const bool leu = a == lab("L4N") || a == lab("L2R"), arg = a == lab("R4N") || a == lab("R2R");
+    t.annot_info[c] = uint8_t(t.annot_id[c] | (leu ? 0x20 : 0) | (arg ? 0x40 : 0));
+  }
   return t;
 }
 
@@ -196,25 +203,35 @@ PFA_HD inline bool base_clean(uint32_t x) {
 }
 
 // Classifier on the set of distinct SENSE codons of one codon column
-// (PolyFastA.py:331-434).  `T` is the table block (host copy or device copy).
-PFA_HD inline uint32_t classify_sense_mask(uint64_t ms, const ct::Tables& T) {
+// (PolyFastA.py:331-434).  `T` is the table block (host copy or device copy);
+// `info` = T.annot_info or a faster copy of it (the kernels keep one in LDS, so
+// that the common cases touch no global memory).
+PFA_HD inline uint32_t classify_sense_mask(uint64_t ms, const ct::Tables& T, const uint8_t* info) {
   const int k = popc64(ms);
   if (k < 2) return 0;                                            // PolyFastA.py:333
   if (k == 2) {
     const int c1 = ctz64(ms);
     const int c2 = ctz64(ms & (ms - 1));
-    return T.pair[c1 * 64 + c2];
+    const uint32_t x = uint32_t(c1 ^ c2);
+    const bool d0 = (x & 0x30u) != 0u, d1 = (x & 0x0Cu) != 0u, d2 = (x & 0x03u) != 0u;
+    if (int(d0) + int(d1) + int(d2) == 1) {                       // one position differs: PolyFastA.py:349-358
+      const uint32_t i1 = info[c1], i2 = info[c2];
+      const bool syn = i1 == i2 || (d0 && (i1 & i2 & 0x60u) != 0u);
+      const uint32_t bit = d0 ? 1u : d1 ? 2u : 4u;
+      return syn ? bit : bit << 3;
+    }
+    return T.pair[c1 * 64 + c2];                                  // PolyFastA.py:360-414
   }
   // three or more distinct sense codons                          PolyFastA.py:415-432
   uint32_t bm0 = 0, bm1 = 0, bm2 = 0;
-  uint64_t lo = 0, hi = 0;  // 4-bit multiplicity counters per annotation id (a label has <= 4 codons... <= 6 < 16)
+  uint64_t lo = 0, hi = 0;  // 4-bit multiplicity counters per annotation id (a label has at most 6 codons)
   uint32_t maxmult = 0;
   for (uint64_t m = ms; m; m &= m - 1) {
     const int c = ctz64(m);
     bm0 |= 1u << (c >> 4);
     bm1 |= 1u << ((c >> 2) & 3);
     bm2 |= 1u << (c & 3);
-    const uint32_t id = T.annot_id[c];
+    const uint32_t id = info[c] & 0x1Fu;
     const uint32_t sh = (id & 15u) * 4u;
     uint32_t v;
     if (id < 16u) { lo += 1ull << sh; v = uint32_t(lo >> sh) & 15u; }

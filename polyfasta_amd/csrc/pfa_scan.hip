@@ -29,6 +29,7 @@
 // Per-chunk partial sums leave through integer atomics (order-independent).
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -66,13 +67,12 @@ struct Geo {
   static constexpr uint32_t WW = 64u * LB;            // sites (= bytes) per LDS tile row
   static constexpr uint32_t LPR = WW / 16u;           // DMA lanes per row
   static constexpr uint32_t RPI = 64u / LPR;          // rows per DMA instruction
-  static constexpr uint32_t TW_CDS = (WW / 48u) * 48u;  // whole codons, 16-byte aligned tile start
-  static constexpr uint32_t NCOD = TW_CDS / 3u;
-  static constexpr uint32_t CPASS = (NCOD + 63u) / 64u;
+  static constexpr uint32_t NCODMAX = (WW + 2u) / 3u;   // codon columns that can END inside one tile
+  static constexpr uint32_t CPASS = (NCODMAX + 63u) / 64u;
 };
 
 struct LdsLayout {
-  uint32_t tile, list, hist, rowmap, hsite, clist, lab, synhist, total;
+  uint32_t tile, list, hist, rowmap, hsite, clist, c1list, carry, cinfo, ainfo, synhist, total;
 };
 
 PFA_HD inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -86,10 +86,13 @@ PFA_HD inline LdsLayout lds_layout(uint32_t lb, uint32_t n_max, bool cds) {
   o.list = round16(n * ww);  // exactly N rows: lanes of the last DMA instruction beyond row N-1 are masked off
   o.hist = o.list + ww;
   o.rowmap = o.hist + round16((n / 2u) * 4u + 4u);
-  o.hsite = o.rowmap + round16(n * 4u);
+  o.hsite = o.rowmap + round16(n * 4u) + (cds ? 16u : 0u);  // hsite[-2], hsite[-1]: last two sites of the previous tile
   o.clist = o.hsite + (cds ? ww * 4u : 0u);
-  o.lab = o.clist + (cds ? 128u : 0u);
-  o.synhist = o.lab + (cds ? 128u : 0u);
+  o.c1list = o.clist + (cds ? 96u : 0u);    // up to 86 codon columns end in one tile
+  o.carry = o.c1list + (cds ? 192u : 0u);
+  o.cinfo = o.carry + (cds ? round16(2u * n) : 0u);   // carry: last two columns of the previous tile, per row
+  o.ainfo = o.cinfo + (cds ? 64u : 0u);     // cinfo: per codon, synonymous-neighbour count | stop << 7
+  o.synhist = o.ainfo + (cds ? 64u : 0u);   // ainfo: LDS copy of Tables::annot_info
   o.total = o.synhist + (cds ? round16(PFA_SYN_BINS * 4u) : 0u);
   return o;
 }
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   const uint32_t lane = threadIdx.x;
   const pfa_desc D = A.descs[blockIdx.x];
   const bool cds = HAS_CDS && (D.flags & PFA_FLAG_CDS) != 0u;
-  const uint32_t TW = cds ? G::TW_CDS : G::WW;
+  constexpr uint32_t TW = G::WW;
   const uint32_t N = D.n_rows, L = D.n_sites;
   if (N == 0u || L == 0u) return;
   const uint32_t n_tiles = (L + TW - 1u) / TW;
@@ -170,7 +173,10 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   uint32_t* const rowmap = reinterpret_cast<uint32_t*>(lds + lo.rowmap);
   uint32_t* const hsite = reinterpret_cast<uint32_t*>(lds + lo.hsite);
   uint8_t* const clist = lds + lo.clist;
-  uint8_t* const lab = lds + lo.lab;
+  uint16_t* const c1list = reinterpret_cast<uint16_t*>(lds + lo.c1list);
+  uint8_t* const carry = lds + lo.carry;
+  uint8_t* const cinfo = lds + lo.cinfo;
+  uint8_t* const ainfo = lds + lo.ainfo;
   uint32_t* const synhist = reinterpret_cast<uint32_t*>(lds + lo.synhist);
 
   const uint32_t nbins = N / 2u;
@@ -178,11 +184,16 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     rowmap[i] = D.row_idx_off != PFA_NO_ROW_IDX ? A.row_idx[D.row_idx_off + i] : i;
   for (uint32_t i = lane; i < nbins; i += 64u) hist[i] = 0u;
   if (cds)
+  {
     for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) synhist[i] = 0u;
+    cinfo[lane] = uint8_t(d_tables.syn3[lane] | (((d_tables.stop_mask >> lane) & 1ull) << 7));
+    ainfo[lane] = d_tables.annot_info[lane];
+  }
   __syncthreads();
 
   // per-lane partial sums of this chunk
   uint32_t acc_S = 0u, acc_bad = 0u;
+  uint32_t carry_va = 0u, carry_vd = 0u;   // tier-1 AND / XOR words of the previous tile's last lane
   unsigned long long acc_H = 0ull;
   uint32_t acc_segS = 0u, acc_segN = 0u, acc_stops = 0u, acc_missing = 0u, acc_syn1 = 0u;
   unsigned long long acc_HS = 0ull, acc_HN = 0ull;
@@ -265,7 +276,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
 
     // ---------------- tier 2: exact allele counts of the variable sites
     const uint32_t slot = lane >> 2, ph = lane & 3u;
-    for (uint32_t p0 = 0; p0 < P; p0 += 16u) {
+    for (uint32_t p0 = 0; p0 < P && !(A.pad & 4u); p0 += 16u) {
       const uint32_t idx = p0 + slot;
       const bool act = idx < P;
       const uint32_t s = list[act ? idx : 0u];
@@ -308,7 +319,8 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       if (act && ph == 0u) {
         const uint32_t hs = NN - sumsq;
         acc_H += hs;
-        if (cds) hsite[s] = hs;
+        if (cds)  // H of the site + which of A, C, T, G occur there (bits 24-27, codon base order)
+          hsite[s] = hs | ((cA ? 1u : 0u) | (cC ? 2u : 0u) | (cT ? 4u : 0u) | (cG ? 8u : 0u)) << 24;
         // second-largest A/C/G/T count (PolyFastA.py:279-281)
         const uint32_t hi1 = umax(cA, cC), lo1 = umin(cA, cC), hi2 = umax(cG, cT), lo2 = umin(cG, cT);
         const uint32_t second = umax(umin(hi1, hi2), umax(lo1, lo2));
@@ -317,81 +329,211 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       }
     }
 
-    // ---------------- coding sequences: codon columns of the tile
-    if (cds) {
+    // ---------------- coding sequences: the codon columns that END in this tile
+    // Tiles stay 256 (64) sites wide and line-aligned; 256 = 1 (mod 3), so the first codon of
+    // tile t starts t mod 3 sites before it.  Those sites (bytes of every row + their H) are
+    // carried over in LDS from the previous tile of this wave's chunk; chunks of coding plans
+    // hold a multiple of 3 tiles, so a chunk always starts on a codon boundary.
+    if (cds && !(A.pad & 1u)) {
       __syncthreads();
-      uint32_t PC = 0u;
+      auto h_at = [&](int rel) -> uint32_t { return hsite[rel]; };   // rel >= -2
+      auto cell = [&](uint32_t r, int rel) -> uint32_t {
+        const uint8_t* q = rel < 0 ? carry + 2u * r + (uint32_t)(2 + rel) : tile8 + r * G::WW + (uint32_t)rel;
+        return *q;
+      };
+      // Given the set M of distinct clean codons of a column (PolyFastA.py:301-315):
+      // synonymous-site numerator, stop flag, S / N labels of its variable positions.
+      auto finish_codon = [&](unsigned long long M, int rel, uint32_t h0, uint32_t h1, uint32_t h2) {
+        const uint32_t k = (uint32_t)__popcll(M);
+        if (k == 0u) { acc_missing += 1u; return; }
+        const uint32_t t3 = syn_thirds_of_mask(M, d_tables);
+        if (k == 1u) acc_syn1 += t3;
+        else atomicAdd(&synhist[k], t3);
+        acc_stops += (M & d_tables.stop_mask) != 0ull;
+        const unsigned long long Ms = M & ~d_tables.stop_mask;
+        if (k < 2u || __popcll(Ms) < 2) return;
+        const uint32_t labels = classify_sense_mask(Ms, d_tables, ainfo);
+        const uint32_t hs[3] = {h0 & 0xFFFFFFu, h1 & 0xFFFFFFu, h2 & 0xFFFFFFu};
 #pragma unroll
-      for (uint32_t pass = 0; pass < G::CPASS; ++pass) {
-        const uint32_t cc = pass * 64u + lane;
-        const uint32_t s0 = 3u * cc;
-        const bool exists = cc < G::NCOD && s0 < lim;
-        const bool full = exists && (s0 + 2u < lim || site0 + s0 + 2u < L);
-        bool isvar = false;
-        if (exists && !full) acc_missing += 1u;     // partial last codon (PolyFastA.py:301-305)
-        if (full) {
-          isvar = (hsite[s0] | hsite[s0 + 1u] | hsite[s0 + 2u]) != 0u;
-          if (!isvar) {
-            const int code = codon_of(tile8[s0], tile8[s0 + 1u], tile8[s0 + 2u]);
-            if (code < 0) acc_missing += 1u;
-            else {
-              acc_syn1 += d_tables.syn3[code];
-              acc_stops += (d_tables.stop_mask >> code) & 1u;
+        for (uint32_t p = 0; p < 3u; ++p) {
+          const bool is_s = (labels >> p) & 1u, is_n = (labels >> (3u + p)) & 1u;
+          if (is_s) { acc_segS += 1u; acc_HS += hs[p]; }
+          if (is_n) { acc_segN += 1u; acc_HN += hs[p]; }
+          if ((is_s || is_n) && A.syn_bm != nullptr) {   // optional per-site S / N bitmaps
+            const uint32_t site = site0 + (uint32_t)(rel + (int)p);   // rel + p may be -2..-1: previous tile
+            const uint64_t w = (uint64_t)(D.tile_off + site / G::WW) * LB + (site % G::WW) % LB;
+            atomicOr(&(is_s ? A.syn_bm : A.non_bm)[w], 1ull << ((site % G::WW) / LB));
+          }
+        }
+      };
+
+      // Register window: every lane looks at the codon columns that END at one of its own
+      // sites.  The three bytes (tier-1 AND word = the consensus byte of a monomorphic site)
+      // and the three "varies" flags come from this lane's and the previous lane's tier-1
+      // words (lane 0: the words carried over from the previous tile), with no LDS traffic
+      // for the 87 % of columns that do not vary.
+      uint32_t xw[2], dw[2];     // per candidate column: 3 consensus bytes, 3 XOR bytes (0 = monomorphic)
+      int endo[2];               // tile-relative site where it ends, or -1
+      if constexpr (LB == 4) {
+        uint32_t pa = __shfl_up(va, 1), pd = __shfl_up(vd, 1);
+        if (lane == 0u) { pa = carry_va; pd = carry_vd; }
+        carry_va = __shfl(va, 63);
+        carry_vd = __shfl(vd, 63);
+        const unsigned long long Wa = (unsigned long long)pa | (unsigned long long)va << 32;
+        const unsigned long long Wd = (unsigned long long)pd | (unsigned long long)vd << 32;
+        const uint32_t o1 = (5u - (site0 + 4u * lane) % 3u) % 3u;   // first own site that ends a codon
+#pragma unroll
+        for (uint32_t it = 0; it < 2u; ++it) {
+          const uint32_t o = o1 + 3u * it;
+          const bool has = o < 4u && 4u * lane + o < lim;
+          xw[it] = (uint32_t)(Wa >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
+          dw[it] = (uint32_t)(Wd >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
+          endo[it] = has ? (int)(4u * lane + o) : -1;
+        }
+      } else {
+        uint32_t a1 = __shfl_up(va, 1), a2 = __shfl_up(va, 2), d1 = __shfl_up(vd, 1), d2 = __shfl_up(vd, 2);
+        if (lane == 0u) { a1 = carry_va >> 8; d1 = carry_vd >> 8; a2 = carry_va & 0xFFu; d2 = carry_vd & 0xFFu; }
+        if (lane == 1u) { a2 = carry_va >> 8; d2 = carry_vd >> 8; }
+        const uint32_t la = __shfl(va, 62) | __shfl(va, 63) << 8, ld = __shfl(vd, 62) | __shfl(vd, 63) << 8;
+        carry_va = la;
+        carry_vd = ld;
+        xw[0] = (a2 & 0xFFu) | (a1 & 0xFFu) << 8 | (va & 0xFFu) << 16;
+        dw[0] = (d2 & 0xFFu) | (d1 & 0xFFu) << 8 | (vd & 0xFFu) << 16;
+        endo[0] = ((site0 + lane) % 3u == 2u && lane < lim) ? (int)lane : -1;
+        xw[1] = dw[1] = 0u;
+        endo[1] = -1;
+      }
+
+      uint32_t PC = 0u, P1 = 0u;
+#pragma unroll
+      for (uint32_t it = 0; it < (LB == 4 ? 2u : 1u); ++it) {
+        bool joint = false, single = false;
+        uint32_t pv = 0u;
+        if (endo[it] >= 0) {
+          const uint32_t w = xw[it], dv = dw[it];
+          const bool v0 = (dv & 0xFFu) != 0u, v1 = (dv & 0xFF00u) != 0u, v2 = (dv & 0xFF0000u) != 0u;
+          const uint32_t nvar = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
+          joint = nvar >= 2u;                                // rare: the codons must be read row by row
+          single = nvar == 1u;                               // one variable position: second pass below
+          pv = v0 ? 0u : v1 ? 1u : 2u;
+          if (nvar == 0u && !(A.pad & 16u)) {
+            // exactly-A/C/G/T test of the three bytes at once: the canonical byte of the 2-bit
+            // code (x >> 1) & 3 is 0x41 + 2 code + 0x0F [code == 2]; a byte is clean iff it equals it
+            const uint32_t t2 = w & 0x060606u;
+            const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
+            const uint32_t bad = (0x414141u + t2 + (e2 << 4) - e2) ^ w;
+            if (bad == 0u) {
+              const uint32_t tt = t2 >> 1;
+              const uint32_t ci = cinfo[((tt & 3u) << 4) | ((tt >> 6) & 0xCu) | ((tt >> 16) & 3u)];
+              acc_syn1 += ci & 7u;
+              acc_stops += ci >> 7;
+            } else {
+              acc_missing += 1u;
             }
           }
         }
-        if (cc < 128u) lab[cc] = 0u;
-        const uint64_t m = __ballot(isvar);
-        if (isvar) clist[PC + mbcnt64(m)] = uint8_t(cc);
-        PC += (uint32_t)__popcll(m);
+        const uint64_t mj = __ballot(joint);
+        if (joint) clist[PC + mbcnt64(mj)] = uint8_t(endo[it]);
+        PC += (uint32_t)__popcll(mj);
+        const uint64_t m1 = __ballot(single);
+        if (single) c1list[P1 + mbcnt64(m1)] = uint16_t((uint32_t)endo[it] | pv << 8);
+        P1 += (uint32_t)__popcll(m1);
       }
-      PC = __builtin_amdgcn_readfirstlane(PC);
-      __syncthreads();
-      for (uint32_t p0 = 0; p0 < PC; p0 += 16u) {
-        const uint32_t idx = p0 + slot;
-        const bool act = idx < PC;
-        const uint32_t cc = clist[act ? idx : 0u];
-        const uint32_t s0 = 3u * cc;
-        const uint8_t* colp = tile8 + s0;
-        unsigned long long M = 0ull;
-        for (uint32_t r = ph; r < N; r += 4u) {
-          const uint8_t* q = colp + r * G::WW;
-          const int code = codon_of(q[0], q[1], q[2]);
-          if (code >= 0) M |= 1ull << code;
-        }
-        M = quad_or(M);
-        if (act && ph == 0u) {
-          const uint32_t k = (uint32_t)__popcll(M);
-          if (k == 0u) acc_missing += 1u;
-          else {
-            atomicAdd(&synhist[k], syn_thirds_of_mask(M, d_tables));
-            acc_stops += (M & d_tables.stop_mask) != 0ull;
-            const uint32_t labels = classify_sense_mask(M & ~d_tables.stop_mask, d_tables);
-#pragma unroll
-            for (uint32_t p = 0; p < 3u; ++p) {
-              const uint32_t hs = hsite[s0 + p];
-              if ((labels >> p) & 1u) { acc_segS += 1u; acc_HS += hs; }
-              if ((labels >> (3u + p)) & 1u) { acc_segN += 1u; acc_HN += hs; }
-            }
-            lab[cc] = uint8_t(labels);
-          }
-        }
-      }
-      if (A.syn_bm != nullptr) {
+      P1 = __builtin_amdgcn_readfirstlane(P1);
+      if (P1 && !(A.pad & 8u)) {
         __syncthreads();
+        // Columns with ONE variable position: the codon set is the consensus codon with every
+        // A/C/G/T allele of that position substituted (rows with another symbol there hold an
+        // unclean codon and drop out, PolyFastA.py:301).  Only that position can be labelled.
+        for (uint32_t idx = lane; idx < P1; idx += 64u) {
+          const uint32_t ent = c1list[idx];
+          const uint32_t p = ent >> 8;
+          const int rel = (int)(ent & 0xFFu) - 2;
+          const uint32_t hv = hsite[rel + (int)p];
+          const uint32_t am = hv >> 24;
+          const uint32_t y0 = cell(0u, rel + (p == 0u ? 1 : 0)), y1 = cell(0u, rel + (p == 2u ? 1 : 2));   // the two fixed bytes
+          const bool ok = base_clean(y0) && base_clean(y1);
+          const uint32_t sh = 4u - 2u * p;
+          const uint32_t base = p == 0u ? base_code(y0) * 4u + base_code(y1)
+                              : p == 1u ? base_code(y0) * 16u + base_code(y1)
+                                        : base_code(y0) * 16u + base_code(y1) * 4u;
+          uint32_t k = 0u, ks = 0u, t3 = 0u, stop = 0u, ids = 0u, fam = 0x60u;
 #pragma unroll
-        for (uint32_t pass = 0; pass < G::CPASS; ++pass) {
-          const uint32_t cc = pass * 64u + lane;
-          const uint32_t lb = cc < G::NCOD ? lab[cc] : 0u;
-          const uint64_t w = (uint64_t)(D.tile_off + tile) * (3u * G::CPASS) + pass * 3u;
-#pragma unroll
-          for (uint32_t p = 0; p < 3u; ++p) {
-            const uint64_t ms = __ballot((lb >> p) & 1u);
-            const uint64_t mn = __ballot((lb >> (3u + p)) & 1u);
-            if (lane == 0u) { A.syn_bm[w + p] = ms; A.non_bm[w + p] = mn; }
+          for (uint32_t e = 0; e < 4u; ++e) {
+            if (ok && ((am >> e) & 1u)) {
+              const uint32_t c = base | (e << sh);
+              const uint32_t ci = cinfo[c];
+              k += 1u;
+              t3 += ci & 7u;
+              if (ci >> 7) stop = 1u;
+              else {
+                const uint32_t ai = ainfo[c];
+                ids |= (ai & 0x1Fu) << (8u * ks);            // annotation ids of the sense codons, one per byte
+                fam &= ai;
+                ks += 1u;
+              }
+            }
+          }
+          if (k == 0u) { acc_missing += 1u; continue; }
+          if (k == 1u) acc_syn1 += t3;
+          else atomicAdd(&synhist[k], t3);
+          acc_stops += stop;
+          if (ks < 2u) continue;
+          bool is_s, is_n;
+          if (ks == 2u) {                                    // two sense codons, one position: PolyFastA.py:349-358
+            is_s = (ids & 0xFFu) == (ids >> 8) || (p == 0u && fam != 0u);
+            is_n = !is_s;
+          } else {                                           // PolyFastA.py:415-432 with one variable position
+            // multiplicity of the most frequent annotation among the 3-4 sense codons
+            const uint32_t a = ids & 0xFFu, b = (ids >> 8) & 0xFFu, c = (ids >> 16) & 0xFFu, d = ks == 4u ? ids >> 24 : 0xFFu;
+            const uint32_t ma = 1u + (a == b) + (a == c) + (a == d), mb = 1u + (b == a) + (b == c) + (b == d);
+            const uint32_t mc = 1u + (c == a) + (c == b) + (c == d);
+            const uint32_t maxmult = umax(umax(ma, mb), mc);   // (d's own multiplicity is covered by its equals)
+            is_s = maxmult >= 2u && maxmult >= ks;
+            is_n = maxmult < 2u;
+          }
+          const uint32_t hs = hv & 0xFFFFFFu;
+          if (is_s) { acc_segS += 1u; acc_HS += hs; }
+          if (is_n) { acc_segN += 1u; acc_HN += hs; }
+          if ((is_s || is_n) && A.syn_bm != nullptr) {
+            const uint32_t site = site0 + (uint32_t)(rel + (int)p);
+            const uint64_t wi = (uint64_t)(D.tile_off + site / G::WW) * LB + (site % G::WW) % LB;
+            atomicOr(&(is_s ? A.syn_bm : A.non_bm)[wi], 1ull << ((site % G::WW) / LB));
           }
         }
       }
+      // the trailing 1-2 sites of an alignment whose length is not a multiple of 3 never form
+      // a clean codon (PolyFastA.py:301-305)
+      if (tile + 1u == n_tiles && (L % 3u) != 0u && lane == 0u) acc_missing += 1u;
+      PC = __builtin_amdgcn_readfirstlane(PC);
+      if (PC && !(A.pad & 2u)) {
+        __syncthreads();
+        // joint walk: GL lanes per codon column, as many as the wave allows (64 for a single
+        // column, 4 when 16 are pending), rows dealt round-robin, butterfly OR of the 64-bit sets
+        uint32_t lg = 2u;                                   // log2(GL)
+        while (lg < 6u && (PC << (lg + 1u)) <= 64u) ++lg;
+        const uint32_t GL = 1u << lg, slots = 64u >> lg;
+        const uint32_t jslot = lane >> lg, jph = lane & (GL - 1u);
+        for (uint32_t p0 = 0; p0 < PC; p0 += slots) {
+          const uint32_t idx = p0 + jslot;
+          const bool act = idx < PC;
+          const int rel = (int)clist[act ? idx : 0u] - 2;
+          unsigned long long M = 0ull;
+          for (uint32_t r = jph; r < N; r += GL) {
+            const int code = codon_of(cell(r, rel), cell(r, rel + 1), cell(r, rel + 2));
+            if (code >= 0) M |= 1ull << code;
+          }
+          for (uint32_t o = 1u; o < GL; o <<= 1) M |= __shfl_xor(M, (int)o);
+          if (act && jph == 0u) finish_codon(M, rel, h_at(rel), h_at(rel + 1), h_at(rel + 2));
+        }
+      }
+      // carry the last two columns (bytes of every row, H of the sites) into the next tile
+      __syncthreads();
+      for (uint32_t i = lane; i < N; i += 64u) {
+        carry[2u * i] = tile8[i * G::WW + G::WW - 2u];
+        carry[2u * i + 1u] = tile8[i * G::WW + G::WW - 1u];
+      }
+      if (lane < 2u) hsite[(int)lane - 2] = hsite[G::WW - 2u + lane];
     }
     __syncthreads();  // tile buffer is reused by the next iteration
   }
@@ -476,10 +618,7 @@ struct pfa_plan {
 
 namespace pfa {
 
-static uint32_t tile_sites_for(uint32_t lb, bool cds) {
-  const uint32_t ww = 64u * lb;
-  return cds ? (ww / 48u) * 48u : ww;
-}
+static uint32_t tile_sites_for(uint32_t lb, bool /*cds*/) { return 64u * lb; }
 static uint32_t lb_for(uint32_t n_max) { return n_max <= kMaxRowsWide ? 4u : 1u; }
 
 template <int LB, int STAGE, bool CDS>
@@ -601,11 +740,6 @@ uint32_t pfa_tile_sites(uint32_t max_rows, uint32_t cds) {
   return pfa::tile_sites_for(pfa::lb_for(max_rows), cds != 0);
 }
 
-uint32_t pfa_sn_words_per_tile(uint32_t max_rows) {
-  const uint32_t ncod = pfa::tile_sites_for(pfa::lb_for(max_rows), true) / 3u;
-  return 3u * ((ncod + 63u) / 64u);
-}
-
 uint32_t pfa_var_words_per_tile(uint32_t max_rows) { return pfa::lb_for(max_rows); }
 
 void pfa_plan_destroy(pfa_plan* p) {
@@ -722,6 +856,10 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
   p->n_chunks = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)max_tiles + tpc - 1) / tpc));
   // balance: the same number of chunks, equal shares (40 tiles in 4 chunks = 10 each, not 13+13+13+1)
   p->tiles_per_chunk = std::max<uint32_t>(1u, (max_tiles + p->n_chunks - 1) / p->n_chunks);
+  if (any_cds) {  // a coding chunk must start on a codon boundary: 3 tiles = 768 (192) sites
+    p->tiles_per_chunk = (p->tiles_per_chunk + 2u) / 3u * 3u;
+    p->n_chunks = std::max<uint32_t>(1u, (max_tiles + p->tiles_per_chunk - 1) / p->tiles_per_chunk);
+  }
 
 #define PLAN_HIP(call)                                                                        \
   do {                                                                                        \
@@ -755,11 +893,8 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
   if (want & PFA_WANT_VAR_BITMAP)
     PLAN_HIP(hipMalloc((void**)&p->d_var_bm, nt * lb * sizeof(uint64_t)));
   if ((want & PFA_WANT_SN_BITMAP) && any_cds) {
-    const size_t w = pfa_sn_words_per_tile(n_max);
-    PLAN_HIP(hipMalloc((void**)&p->d_syn_bm, nt * w * sizeof(uint64_t)));
-    PLAN_HIP(hipMalloc((void**)&p->d_non_bm, nt * w * sizeof(uint64_t)));
-    PLAN_HIP(hipMemsetAsync(p->d_syn_bm, 0, nt * w * sizeof(uint64_t), st));
-    PLAN_HIP(hipMemsetAsync(p->d_non_bm, 0, nt * w * sizeof(uint64_t), st));
+    PLAN_HIP(hipMalloc((void**)&p->d_syn_bm, nt * lb * sizeof(uint64_t)));
+    PLAN_HIP(hipMalloc((void**)&p->d_non_bm, nt * lb * sizeof(uint64_t)));
   }
   for (int i = 0; i < pfa::kEventRing; ++i) {
     PLAN_HIP(hipEventCreate(&p->ev0[i]));
@@ -776,6 +911,11 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   if (!p || !d_bases) { pfa::set_error("pfa_plan_run: NULL argument"); return PFA_ERR_ARG; }
   hipStream_t st = pfa::ctx().stream;
   PFA_HIP(hipMemsetAsync(p->d_slab, 0, p->slab_bytes, st));
+  if (p->d_syn_bm) {  // S / N bitmaps are built with atomicOr: clear them every run
+    const size_t nb = std::max<size_t>(1, p->n_tiles_total) * p->lb * sizeof(uint64_t);
+    PFA_HIP(hipMemsetAsync(p->d_syn_bm, 0, nb, st));
+    PFA_HIP(hipMemsetAsync(p->d_non_bm, 0, nb, st));
+  }
 
   pfa::ScanArgs a;
   a.bases = d_bases;
@@ -790,7 +930,7 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   a.n_desc = p->n_desc;
   a.tiles_per_chunk = p->tiles_per_chunk;
   a.n_max = p->n_max;
-  a.pad = 0;
+  { const char* e = getenv("PFA_ABLATE"); a.pad = e ? (uint32_t)atoi(e) : 0u; }  // timing experiments only
 
   const int slot = (int)(p->n_runs % pfa::kEventRing);
   PFA_HIP(hipEventRecord(p->ev0[slot], st));
@@ -844,7 +984,7 @@ int pfa_plan_fetch(pfa_plan* p, pfa_result* results, uint32_t* sfs, uint32_t* sy
   }
   if (syn_bitmap || non_bitmap) {
     if (!p->d_syn_bm) { pfa::set_error("pfa_plan_fetch: plan has no S/N bitmaps"); return PFA_ERR_ARG; }
-    const size_t w = pfa_sn_words_per_tile(p->n_max);
+    const size_t w = p->lb;
     if (syn_bitmap && nt) PFA_HIP(hipMemcpyAsync(syn_bitmap, p->d_syn_bm, nt * w * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     if (non_bitmap && nt) PFA_HIP(hipMemcpyAsync(non_bitmap, p->d_non_bm, nt * w * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   }
@@ -890,9 +1030,8 @@ int pfa_scan_batch(const uint8_t* bases, uint64_t n_bases_bytes, const pfa_desc*
 int64_t pfa_bitmap_positions(const uint64_t* words, uint32_t n_tiles, uint32_t words_per_tile,
                              uint32_t tile_sites, uint32_t n_sites, uint32_t* pos_out, uint64_t cap) {
   if (!words || (!pos_out && cap)) { pfa::set_error("pfa_bitmap_positions: NULL argument"); return PFA_ERR_ARG; }
-  // bit l of word w of a tile <-> tile-local site  per_lane * (64 * (w / per_lane) + l) + w % per_lane
-  // with per_lane = 4 or 1 (variable-site bitmap: words_per_tile = per_lane) or 3 (S/N bitmaps).
-  const uint32_t per_lane = (words_per_tile % 3u == 0u) ? 3u : words_per_tile;
+  // bit l of word b of a tile <-> tile-local site  words_per_tile * l + b
+  const uint32_t per_lane = words_per_tile;
   uint64_t n = 0;
   for (uint32_t t = 0; t < n_tiles; ++t) {
     const uint64_t* w = words + (uint64_t)t * words_per_tile;
@@ -916,7 +1055,7 @@ int64_t pfa_bitmap_positions(const uint64_t* words, uint32_t n_tiles, uint32_t w
 }
 
 uint32_t pfa_classify_codon_mask(uint64_t mask) {
-  return pfa::classify_sense_mask(mask & ~pfa::kHostTables.stop_mask, pfa::kHostTables);
+  return pfa::classify_sense_mask(mask & ~pfa::kHostTables.stop_mask, pfa::kHostTables, pfa::kHostTables.annot_info);
 }
 
 uint32_t pfa_codon_syn_thirds(uint32_t codon) { return codon < 64u ? pfa::kHostTables.syn3[codon] : 0u; }

@@ -67,9 +67,7 @@ class UnitTable:
     n_bases_bytes: int
     n_max: int = 0
     tile_sites: int = 256
-    tile_sites_cds: int = 240
     var_words: int = 4
-    sn_words: int = 6
     n_tiles: np.ndarray = field(default=None)
 
     @property
@@ -83,9 +81,7 @@ def finalize_layout(descs: np.ndarray, row_idx, n_bases_bytes: int) -> UnitTable
     descs = np.ascontiguousarray(descs, dtype=DESC_DTYPE)
     n_max = int(descs["n_rows"].max()) if len(descs) else 0
     tw = int(lib.pfa_tile_sites(n_max, 0))
-    twc = int(lib.pfa_tile_sites(n_max, 1))
-    cds = (descs["flags"] & PFA_FLAG_CDS) != 0
-    width = np.where(cds, twc, tw).astype(np.int64)
+    width = np.int64(tw)
     live = (descs["n_rows"] > 0) & (descs["n_sites"] > 0)
     n_tiles = np.where(live, (descs["n_sites"].astype(np.int64) + width - 1) // width, 0)
     bins = descs["n_rows"].astype(np.int64) // 2
@@ -93,8 +89,7 @@ def finalize_layout(descs: np.ndarray, row_idx, n_bases_bytes: int) -> UnitTable
     descs["tile_off"] = np.concatenate(([0], np.cumsum(n_tiles)[:-1])) if len(descs) else 0
     ri = np.ascontiguousarray(row_idx if row_idx is not None else np.zeros(0), dtype=np.uint32)
     return UnitTable(descs=descs, row_idx=ri, n_bases_bytes=int(n_bases_bytes), n_max=n_max,
-                     tile_sites=tw, tile_sites_cds=twc, var_words=int(lib.pfa_var_words_per_tile(n_max)),
-                     sn_words=int(lib.pfa_sn_words_per_tile(n_max)), n_tiles=n_tiles)
+                     tile_sites=tw, var_words=int(lib.pfa_var_words_per_tile(n_max)), n_tiles=n_tiles)
 
 
 class Batch:
@@ -189,15 +184,13 @@ class ScanOutput:
 
     def var_positions(self, i: int) -> np.ndarray:
         """ascending positions of the variable sites of unit i (``pos`` of getvarsites)"""
-        cds = bool(self.table.descs[i]["flags"] & PFA_FLAG_CDS)
-        tw = self.table.tile_sites_cds if cds else self.table.tile_sites
-        return self._positions(self.var_bitmap, i, self.table.var_words, tw)
+        return self._positions(self.var_bitmap, i, self.table.var_words, self.table.tile_sites)
 
     def syn_positions(self, i: int) -> np.ndarray:
-        return self._positions(self.syn_bitmap, i, self.table.sn_words, self.table.tile_sites_cds)
+        return self._positions(self.syn_bitmap, i, self.table.var_words, self.table.tile_sites)
 
     def non_positions(self, i: int) -> np.ndarray:
-        return self._positions(self.non_bitmap, i, self.table.sn_words, self.table.tile_sites_cds)
+        return self._positions(self.non_bitmap, i, self.table.var_words, self.table.tile_sites)
 
 
 class Plan:
@@ -232,8 +225,8 @@ class Plan:
         syn = np.zeros((t.n_units, PFA_SYN_BINS), dtype=np.uint32) if self.any_cds else None
         vb = np.zeros(max(nt * t.var_words, 1), dtype=np.uint64) if self.want & _lib.PFA_WANT_VAR_BITMAP else None
         sn = bool(self.want & _lib.PFA_WANT_SN_BITMAP) and self.any_cds
-        sb = np.zeros(max(nt * t.sn_words, 1), dtype=np.uint64) if sn else None
-        nb = np.zeros(max(nt * t.sn_words, 1), dtype=np.uint64) if sn else None
+        sb = np.zeros(max(nt * t.var_words, 1), dtype=np.uint64) if sn else None
+        nb = np.zeros(max(nt * t.var_words, 1), dtype=np.uint64) if sn else None
         _lib.check(lib.pfa_plan_fetch(self.handle, _lib.ptr(res), _lib.ptr(sfs), _lib.ptr(syn), _lib.ptr(vb),
                                       _lib.ptr(sb), _lib.ptr(nb)))
         return ScanOutput(table=t, results=res, sfs_flat=sfs, syn_num=syn, var_bitmap=vb, syn_bitmap=sb, non_bitmap=nb)

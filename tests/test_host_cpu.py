@@ -146,11 +146,9 @@ def test_bitmap_expansion():
     assert out[:n].tolist() == [0, 7, 252, 265]
     assert lib.pfa_bitmap_positions(_lib.ptr(words), 2, 4, 256, 260, _lib.ptr(out), 16) == 3   # site >= n_sites dropped
     assert lib.pfa_bitmap_positions(_lib.ptr(words), 2, 4, 256, 300, _lib.ptr(out), 2) < 0
-    sn = np.zeros(6, dtype=np.uint64)
-    sn[2] = 1                         # group 0, p = 2, lane 0 -> site 2
-    sn[3] = 1 << 15                   # group 1, p = 0, lane 15 -> site 3*(64+15) = 237
-    n = lib.pfa_bitmap_positions(_lib.ptr(sn), 1, 6, 240, 240, _lib.ptr(out), 16)
-    assert out[:n].tolist() == [2, 237]
+    narrow = np.array([1 | (1 << 63), 2], dtype=np.uint64)      # 64-site tiles: one word each
+    n = lib.pfa_bitmap_positions(_lib.ptr(narrow), 2, 1, 64, 128, _lib.ptr(out), 16)
+    assert out[:n].tolist() == [0, 63, 65]
 
 
 def test_batch_packing_and_layout():
@@ -165,7 +163,7 @@ def test_batch_packing_and_layout():
     d = t.descs
     assert d["row_stride"].tolist() == [1024, 128, 1024] and (d["base_off"] % 256 == 0).all()
     assert d["n_rows"].tolist() == [5, 3, 5] and d["sfs_off"].tolist() == [0, 2, 3]
-    assert t.n_tiles.tolist() == [4, 1, 5] and d["tile_off"].tolist() == [0, 4, 5]
+    assert t.n_tiles.tolist() == [4, 1, 4] and d["tile_off"].tolist() == [0, 4, 5]
     assert t.row_idx.tolist() == [0, 6, 3] and d["row_idx_off"].tolist() == [_lib.PFA_NO_ROW_IDX, 0, _lib.PFA_NO_ROW_IDX]
     assert (bases[int(d["base_off"][1]):int(d["base_off"][1]) + 30] == 67).all()
 
