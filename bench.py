@@ -76,6 +76,24 @@ def cpu_baseline(args, params):
             "host_cores": os.cpu_count()}, (s, h)
 
 
+def measured_traffic(cfg):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this exact
+    workload (profiles/*_pmc_summary.json, made by tools/gpu_prof.sh +
+    tools/summarize_prof.py: separate --pmc passes, gfx950 correction), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        w = j.get("workload", {})
+        if all(w.get(k) == cfg.get(k) for k in ("rows", "sites", "batch_per_gpu", "row_stride", "kernel_variant")) \
+                and ("coding" in w.get("workload", "")) == ("coding" in cfg.get("workload", "")):
+            best = j.get("traffic_bytes_per_launch")
+    return best
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -191,6 +209,7 @@ def main():
                       "sum_H": int(res["H"].sum()),
                       "gathered_records": None if gathered is None else int(len(gathered))},
         }
+        line["roofline"]["traffic"] = measured_traffic(line["config"])
         if world == 1 and not args.no_cpu_baseline and not args.coding and not args.pops:
             cb, (s_cpu, h_cpu) = cpu_baseline(args, params)
             line["cpu_baseline"] = cb
