@@ -103,11 +103,15 @@ def main():
         args.gpus = world
 
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PFA_FORCE_DIST"):   # PFA_FORCE_DIST: rehearse the RCCL path on one GPU
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        from polyfasta_amd.dist import stdout_to_stderr
+        with stdout_to_stderr():         # RCCL's version banner must not join the one JSON line on stdout
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
     from polyfasta_amd import _lib, scan, synth
 
     lib = _lib.load()

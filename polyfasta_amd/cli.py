@@ -319,7 +319,7 @@ def main(argv=None):
 
     from .dist import Group, env_world, shard_indices
     rank, _, world = env_world()
-    group = Group() if world > 1 else None
+    group = Group() if (world > 1 or os.environ.get("PFA_FORCE_DIST")) else None
 
     sink = Sink(args.out, args.silent)
     if rank == 0:

@@ -18,6 +18,26 @@ import os
 import numpy as np
 
 
+import contextlib
+import sys
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner on stdout when the first communicator is built;
+    stdout carries the CSV rows (or the bench's one JSON line), so file descriptor 1
+    is pointed at stderr while the process group comes up."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def env_world():
     """(rank, local_rank, world) from the launcher's environment (torch.distributed.run)."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
@@ -43,11 +63,13 @@ class Group:
         self.backend = backend
         self.device = torch.device("cuda", self.local_rank) if backend == "nccl" else torch.device("cpu")
         if not dist.is_initialized():
-            if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
-                dist.init_process_group(backend="nccl", device_id=self.device)
-            else:
-                dist.init_process_group(backend="gloo")
+            with stdout_to_stderr():
+                if backend == "nccl":
+                    torch.cuda.set_device(self.local_rank)
+                    dist.init_process_group(backend="nccl", device_id=self.device)
+                else:
+                    dist.init_process_group(backend="gloo")
+                self.barrier()          # builds the communicator now (banner, lazy init) rather than mid-output
 
     def barrier(self):
         if self.backend == "nccl":
