@@ -77,19 +77,21 @@ struct LdsLayout {
 
 PFA_HD inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
 
-PFA_HD inline LdsLayout lds_layout(uint32_t lb, uint32_t n_max, bool cds) {
+PFA_HD inline LdsLayout lds_layout(uint32_t lb, uint32_t n_max, bool cds, bool rowmap) {
   const uint32_t ww = 64u * lb, rpi = 1024u / ww;
   const uint32_t n = n_max ? n_max : 1u;
   LdsLayout o;
   o.tile = 0;
   (void)rpi;
   o.list = round16(n * ww);  // exactly N rows: lanes of the last DMA instruction beyond row N-1 are masked off
-  o.hist = o.list + ww;
+  // `list` (tier-2 site list, ww bytes) is dead once tier 2 is done: the coding pass reuses the
+  // region for its two codon lists (up to 86 entries: 96 B of u8 + 176 B of u16)
+  o.hist = o.list + (cds ? (ww > 272u ? ww : 272u) : ww);
+  o.clist = o.list;
+  o.c1list = o.list + 96u;
   o.rowmap = o.hist + round16((n / 2u) * 4u + 4u);
-  o.hsite = o.rowmap + round16(n * 4u) + (cds ? 16u : 0u);  // hsite[-2], hsite[-1]: last two sites of the previous tile
-  o.clist = o.hsite + (cds ? ww * 4u : 0u);
-  o.c1list = o.clist + (cds ? 96u : 0u);    // up to 86 codon columns end in one tile
-  o.carry = o.c1list + (cds ? 192u : 0u);
+  o.hsite = o.rowmap + (rowmap ? round16(n * 4u) : 0u) + (cds ? 16u : 0u);  // hsite[-2], hsite[-1]: last two sites of the previous tile
+  o.carry = o.hsite + (cds ? ww * 4u : 0u);
   o.cinfo = o.carry + (cds ? round16(2u * n) : 0u);   // carry: last two columns of the previous tile, per row
   o.ainfo = o.cinfo + (cds ? 64u : 0u);     // cinfo: per codon, synonymous-neighbour count | stop << 7
   o.synhist = o.ainfo + (cds ? 64u : 0u);   // ainfo: LDS copy of Tables::annot_info
@@ -110,7 +112,9 @@ struct ScanArgs {
   uint32_t n_desc;
   uint32_t tiles_per_chunk;
   uint32_t n_max;
-  uint32_t pad;
+  uint32_t pad;        // ablation bits (timing experiments)
+  uint32_t use_rowmap; // 1 when some unit carries a row-index list
+  uint32_t pad2;
 };
 
 // ---------------------------------------------------------------- device helpers
@@ -166,7 +170,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   if (t0 >= n_tiles) return;
   const uint32_t t1 = umin(t0 + A.tiles_per_chunk, n_tiles);
 
-  const LdsLayout lo = lds_layout(LB, A.n_max, HAS_CDS);
+  const LdsLayout lo = lds_layout(LB, A.n_max, HAS_CDS, A.use_rowmap != 0u);
   uint8_t* const tile8 = lds + lo.tile;
   uint8_t* const list = lds + lo.list;
   uint32_t* const hist = reinterpret_cast<uint32_t*>(lds + lo.hist);
@@ -180,8 +184,9 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   uint32_t* const synhist = reinterpret_cast<uint32_t*>(lds + lo.synhist);
 
   const uint32_t nbins = N / 2u;
-  for (uint32_t i = lane; i < N; i += 64u)
-    rowmap[i] = D.row_idx_off != PFA_NO_ROW_IDX ? A.row_idx[D.row_idx_off + i] : i;
+  const bool mapped = D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
+  if (mapped)
+    for (uint32_t i = lane; i < N; i += 64u) rowmap[i] = A.row_idx[D.row_idx_off + i];
   for (uint32_t i = lane; i < nbins; i += 64u) hist[i] = 0u;
   if (cds)
   {
@@ -215,7 +220,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
         for (uint32_t g = 0; g < n_inst; ++g) {
           const uint32_t r = g * G::RPI + rr;
           if (r < N) {  // EXEC-masked lanes move nothing and leave their LDS slot untouched
-            const uint8_t* src = mat + (uint64_t)rowmap[r] * D.row_stride + col;
+            const uint8_t* src = mat + (uint64_t)(mapped ? rowmap[r] : r) * D.row_stride + col;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
           }
         }
@@ -225,7 +230,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
         for (uint32_t g = 0; g < n_inst; ++g) {
           const uint32_t r = g * G::RPI + rr;
           if (r < N) {
-            const uint4 v = *reinterpret_cast<const uint4*>(mat + (uint64_t)rowmap[r] * D.row_stride + col);
+            const uint4 v = *reinterpret_cast<const uint4*>(mat + (uint64_t)(mapped ? rowmap[r] : r) * D.row_stride + col);
             *reinterpret_cast<uint4*>(tile8 + g * 1024u + lane * 16u) = v;
           }
         }
@@ -595,6 +600,7 @@ struct pfa_plan {
   uint32_t n_chunks = 1;
   uint32_t want = 0;
   bool any_cds = false;
+  bool use_rowmap = false;
   uint64_t sfs_words = 0;
   uint64_t n_bases_bytes = 0;
   uint32_t lds_bytes = 0;
@@ -839,7 +845,8 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
   p->n_tiles_total = (uint32_t)tiles_total;
   p->max_tiles = max_tiles;
   p->n_bases_bytes = n_bases_bytes;
-  p->lds_bytes = pfa::lds_layout(lb, n_max, any_cds).total;
+  p->use_rowmap = n_row_idx != 0;
+  p->lds_bytes = pfa::lds_layout(lb, n_max, any_cds, p->use_rowmap).total;
 
   // chunking: enough single-wave workgroups to fill 256 CUs several times over,
   // but whole alignments per wave once the batch is large (fewer atomics)
@@ -930,6 +937,8 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   a.n_desc = p->n_desc;
   a.tiles_per_chunk = p->tiles_per_chunk;
   a.n_max = p->n_max;
+  a.use_rowmap = p->use_rowmap ? 1u : 0u;
+  a.pad2 = 0;
   { const char* e = getenv("PFA_ABLATE"); a.pad = e ? (uint32_t)atoi(e) : 0u; }  // timing experiments only
 
   const int slot = (int)(p->n_runs % pfa::kEventRing);

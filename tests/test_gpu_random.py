@@ -1,0 +1,86 @@
+"""Randomised GPU-vs-oracle parity over shapes, alphabets, strides and row
+subsets (hash-seeded, reproducible).  Integers must match exactly."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from polyfasta_amd import scan, synth
+from tests import _cases as C
+
+pytestmark = pytest.mark.gpu
+
+ALPHABETS = [b"ACGT", b"ACGT-", b"ACGTN-", b"ACGTRYKMSWBDHVN-?", b"AC", b"-N", b"ACGTU*.@EFPQVW"]
+
+
+def _random_matrix(rng, n, L, alphabet, p_mut):
+    """consensus row + per-cell substitutions at rate p_mut: many monomorphic
+    columns, some multi-allelic, some all-odd-symbol columns"""
+    a = np.frombuffer(alphabet, dtype=np.uint8)
+    cons = a[rng.integers(0, len(a), size=L)]
+    m = np.tile(cons, (n, 1))
+    hit = rng.random((n, L)) < p_mut
+    m[hit] = a[rng.integers(0, len(a), size=int(hit.sum()))]
+    return m
+
+
+def _compare(out, i, o, cds):
+    r = out.results[i]
+    assert (int(r["seg_sites"]), int(r["H"]), int(r["sfs_bad"])) == (o["S"], o["H"], o["sfs_bad"])
+    assert out.sfs(i).tolist() == o["sfs"].tolist()
+    assert out.var_positions(i).tolist() == np.flatnonzero(o["h_site"]).tolist()
+    if cds:
+        assert (int(r["seg_S"]), int(r["seg_N"]), int(r["H_S"]), int(r["H_N"]), int(r["nstops"]), int(r["missing_cols"])) == \
+               (o["seg_S"], o["seg_N"], o["H_S"], o["H_N"], o["nstops"], o["missing_cols"])
+        assert out.syn_positions(i).tolist() == np.flatnonzero(o["labels"] == 1).tolist()
+        assert out.non_positions(i).tolist() == np.flatnonzero(o["labels"] == 2).tolist()
+        from polyfasta_amd import stats
+        assert abs(stats.syn_sites_from_bins(out.syn_num[i]) - o["count_syn"]) <= 1e-9 * max(1.0, o["count_syn"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_batches(gpu, seed):
+    rng = np.random.default_rng(1234 + seed)
+    b = scan.Batch(stride_align=[16, 32, 128, 256, 16, 64][seed])
+    units = []
+    for _ in range(60):
+        n = int(rng.choice([1, 2, 3, 4, 5, 8, 17, 33, 50, 64, 65, 100, 129, 255, 300]))
+        L = int(rng.choice([1, 2, 3, 4, 15, 16, 17, 47, 48, 49, 63, 64, 65, 255, 256, 257, 511, 512, 513, 767, 768, 769, 770, 1000, 1537, 3001]))
+        alpha = ALPHABETS[int(rng.integers(0, len(ALPHABETS)))]
+        m = _random_matrix(rng, n, L, alpha, float(rng.choice([0.0, 0.001, 0.01, 0.05, 0.3])))
+        mid = b.add_matrix(m)
+        for cds in (False, True):
+            b.add_unit(mid, cds=cds)
+            units.append((m, None, cds))
+        if n >= 3:
+            rows = np.sort(rng.choice(n, size=int(rng.integers(1, n + 1)), replace=False)).astype(np.uint32)
+            if rng.random() < 0.3:
+                rows = rows[::-1].copy()
+            cds = bool(rng.random() < 0.5)
+            b.add_unit(mid, rows=rows, cds=cds)
+            units.append((m, rows, cds))
+    out = scan.scan_batch(b, want_pos=True, want_sn=True)
+    for i, (m, rows, cds) in enumerate(units):
+        _compare(out, i, c_oracle.scan(m, rows=rows, cds=cds, want_sites=True), cds)
+
+
+def test_random_many_rows(gpu):
+    """plans whose largest unit has more than 600 rows run the 64-site-tile kernel for every unit"""
+    rng = np.random.default_rng(99)
+    b = scan.Batch()
+    units = []
+    for n, L in ((700, 130), (50, 1000), (2048, 65), (3, 64), (1025, 385)):
+        m = _random_matrix(rng, n, L, b"ACGTN-", 0.01)
+        mid = b.add_matrix(m)
+        for cds in (False, True):
+            b.add_unit(mid, cds=cds)
+            units.append((m, None, cds))
+    out = scan.scan_batch(b, want_pos=True, want_sn=True)
+    for i, (m, rows, cds) in enumerate(units):
+        _compare(out, i, c_oracle.scan(m, rows=rows, cds=cds, want_sites=True), cds)
+
+
+def test_too_many_rows_is_refused(gpu):
+    from polyfasta_amd import _lib
+    with pytest.raises(_lib.PfaError) as e:
+        scan.scan_matrix(np.full((2049, 32), 65, dtype=np.uint8))
+    assert e.value.code == -5

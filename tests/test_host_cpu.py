@@ -178,3 +178,13 @@ def test_row_formatting_matches_reference_rows():
     res["seg_sites"], res["H"] = g1["S"], g1["H"]
     row = cli.format_plain_row("file1.fa", "NA", 20, 1000, res, False)
     C.rows_close(row, "file1.fa,1000,NA,20,87,0.01410000000000001,0.024522656228401073,-1.7406412034629681")
+
+
+def test_plain_c_program_links_against_the_abi(tmp_path):
+    import subprocess
+    exe = tmp_path / "abi_smoke"
+    lib_dir = os.path.join(ROOT, "polyfasta_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", os.path.join(ROOT, "tests", "abi_smoke.c"), "-o", str(exe),
+                           f"-L{lib_dir}", "-lpfa_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "abi ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
