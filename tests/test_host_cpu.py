@@ -188,3 +188,22 @@ def test_plain_c_program_links_against_the_abi(tmp_path):
                            f"-L{lib_dir}", "-lpfa_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "abi ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+def test_fasta_packer_differential_vs_oracle_reader():
+    """Random byte soup over the characters that matter ('>' newlines, CR, blanks, control
+    whitespace, lower case): the native packer and the oracle's restatement of readfasta
+    must agree record for record."""
+    import io
+    import random
+    from oracle import polyfasta_oracle as orc
+    rng = random.Random(7)
+    alphabet = [">", "\n", "\r", "\r\n", " ", "A", "c", "-", "\t", "\x1c", "G", "n", ">x", "\n>", "T", "\x0b", "\x0c"]
+    for _ in range(3000):
+        text = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 40)))
+        want = orc.parse_fasta_lines(io.StringIO(text, newline=None))
+        got = fasta.parse_fasta_bytes(text.encode())
+        if want is None:
+            assert got is None, repr(text)
+        else:
+            assert got is not None and got.to_dict() == want, (repr(text), got.to_dict() if got else None, want)
