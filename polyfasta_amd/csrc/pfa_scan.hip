@@ -514,7 +514,9 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       if (PC && !(A.pad & 2u)) {
         __syncthreads();
         // joint walk: GL lanes per codon column, as many as the wave allows (64 for a single
-        // column, 4 when 16 are pending), rows dealt round-robin, butterfly OR of the 64-bit sets
+        // column, 4 when 16 are pending), rows dealt round-robin; the lanes of a column OR their
+        // 64-bit codon sets into one LDS word (ds_or_b64) — cheaper than a 6-step 64-bit butterfly
+        unsigned long long* const jacc = reinterpret_cast<unsigned long long*>(c1list);   // c1list is dead by now
         uint32_t lg = 2u;                                   // log2(GL)
         while (lg < 6u && (PC << (lg + 1u)) <= 64u) ++lg;
         const uint32_t GL = 1u << lg, slots = 64u >> lg;
@@ -524,12 +526,16 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
           const bool act = idx < PC;
           const int rel = (int)clist[act ? idx : 0u] - 2;
           unsigned long long M = 0ull;
+          if (jph == 0u) jacc[jslot] = 0ull;
           for (uint32_t r = jph; r < N; r += GL) {
             const int code = codon_of(cell(r, rel), cell(r, rel + 1), cell(r, rel + 2));
             if (code >= 0) M |= 1ull << code;
           }
-          for (uint32_t o = 1u; o < GL; o <<= 1) M |= __shfl_xor(M, (int)o);
-          if (act && jph == 0u) finish_codon(M, rel, h_at(rel), h_at(rel + 1), h_at(rel + 2));
+          __syncthreads();
+          if (M != 0ull) atomicOr(&jacc[jslot], M);
+          __syncthreads();
+          if (act && jph == 0u) finish_codon(jacc[jslot], rel, h_at(rel), h_at(rel + 1), h_at(rel + 2));
+          __syncthreads();
         }
       }
       // carry the last two columns (bytes of every row, H of the sites) into the next tile
