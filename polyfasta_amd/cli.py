@@ -30,22 +30,22 @@ HEADER_CDS = ("file,sites_S,sites_N,pop,N,seg_sites_S,seg_sites_N,pi_S,pi_N,thet
               "tajimasD_S,tajimasD_N,nstops")
 NO_VAR = "0,0,0,NA"
 
-# ingest buffer (pinned host memory, allocated once per process) and files per loader call
-BATCH_BYTES = 512 << 20
+# two pinned ingest buffers (allocated once per process): the loader threads fill one while
+# the other is uploaded and scanned
+BATCH_BYTES = 384 << 20
 FILES_PER_CALL = 8192
-_pinned_cache = None
+_pinned_cache = [None, None]
 
 
-def _ingest_buffer(min_bytes=0):
-    """The process-wide pinned ingest buffer (hipHostMalloc costs ~60 ms per GB, so
-    it is sized once and reused by every batch)."""
-    global _pinned_cache
+def _ingest_buffer(slot, min_bytes=0):
+    """Process-wide pinned ingest buffers (hipHostMalloc costs ~60 ms per GB, so they
+    are sized once and reused by every batch)."""
     want = max(BATCH_BYTES, int(min_bytes))
-    if _pinned_cache is None or len(_pinned_cache.array) < want:
-        if _pinned_cache is not None:
-            _pinned_cache.free()
-        _pinned_cache = fasta.PinnedBuffer(want)
-    return _pinned_cache
+    if _pinned_cache[slot] is None or len(_pinned_cache[slot].array) < want:
+        if _pinned_cache[slot] is not None:
+            _pinned_cache[slot].free()
+        _pinned_cache[slot] = fasta.PinnedBuffer(want)
+    return _pinned_cache[slot]
 
 
 def format_plain_row(name, pop, n_rows, seqlen, res, jc):
@@ -192,63 +192,102 @@ def process_files(indexed_paths, args):
             _attach(pending, scan_batch(batch) if batch.n_units else None, done)
         return done
 
-    todo = list(indexed_paths)
-    pinned = _ingest_buffer()
-    while todo:
-        chunk, todo = todo[:FILES_PER_CALL], todo[FILES_PER_CALL:]
-        bases = pinned.array
-        info, names, used = fasta.load_files([p for _, p in chunk], bases, stride_align=128,
-                                             want_names=bool(args.pops))
-        status = info["status"]
-        if (status == PFA_ERR_IO).any():
-            path = chunk[int(np.flatnonzero(status == PFA_ERR_IO)[0])][1]
-            open(path, "rb").close()          # raises the OSError the reference would raise (:239)
-            raise OSError(f"cannot read {path}")
-        deferred = [chunk[k] for k in np.flatnonzero(status == PFA_FILE_DEFERRED)]
-        descs, ridx, pending = [], None, []
-        if not args.pops:
-            # one unit per packed file: build the descriptor table without a Python loop
-            ok = np.flatnonzero(status == 0)
-            descs = np.zeros(len(ok), dtype=DESC_DTYPE)
-            for f in ("base_off", "n_sites", "row_stride"):
-                descs[f] = info[f][ok]
-            descs["n_rows"] = descs["mat_rows"] = info["n_rows"][ok]
-            descs["row_idx_off"] = PFA_NO_ROW_IDX
-            descs["flags"] = PFA_FLAG_CDS if args.cds else 0
-            unit_of = dict(zip(ok.tolist(), range(len(ok))))
-            for k, fi in enumerate(info.tolist()):
-                st = fi[0]
-                if st == PFA_FILE_DEFERRED:
-                    continue
-                fidx, path = chunk[k]
-                pending += _events_for(fidx, path, path.split("/")[-1], st, None, fi[1], fi[2], args,
-                                       lambda rows, k=k: unit_of[k])
-        else:
-            dl, rl = [], []
-            for k, fi in enumerate(info):
-                st = int(fi["status"])
-                if st == PFA_FILE_DEFERRED:
-                    continue
-                fidx, path = chunk[k]
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    queue = deque(indexed_paths)
+    want_names = bool(args.pops)
 
-                def add_unit(rows, fi=fi):
-                    d = np.zeros(1, dtype=DESC_DTYPE)[0]
-                    d["base_off"], d["n_sites"], d["row_stride"], d["mat_rows"] = fi["base_off"], fi["n_sites"], fi["row_stride"], fi["n_rows"]
-                    d["flags"] = PFA_FLAG_CDS if args.cds else 0
-                    d["n_rows"], d["row_idx_off"] = len(rows), sum(len(r) for r in rl)
-                    rl.append(np.asarray(rows, dtype=np.uint32))
-                    dl.append(d)
-                    return len(dl) - 1
-                pending += _events_for(fidx, path, path.split("/")[-1], st, names[k], int(fi["n_rows"]),
-                                       int(fi["n_sites"]), args, add_unit)
-            descs = np.array(dl, dtype=DESC_DTYPE) if dl else []
-            ridx = np.concatenate(rl) if rl else None
-        if len(deferred) == len(chunk):
-            # nothing fitted: the first file alone is larger than the buffer -> grow it
-            pinned = _ingest_buffer((int(info[0]["row_stride"]) << 8) + (1 << 20))
-        out = _scan_table(bases, used, descs, ridx) if len(descs) else None
-        _attach(pending, out, done)
-        todo = deferred + todo
+    def next_chunk(cap):
+        """files whose text adds up to at most ~85 % of a buffer (packed size ~ text size)"""
+        chunk, size = [], 0
+        while queue and len(chunk) < FILES_PER_CALL:
+            try:
+                sz = os.path.getsize(queue[0][1])
+            except OSError:
+                sz = 0
+            if chunk and size + sz > 0.85 * cap:
+                break
+            chunk.append(queue.popleft())
+            size += sz
+        return chunk
+
+    def load(chunk, slot, min_bytes=0):
+        buf = _ingest_buffer(slot, min_bytes)
+        return chunk, buf, fasta.load_files([p for _, p in chunk], buf.array, stride_align=128, want_names=want_names)
+
+    pool = ThreadPoolExecutor(max_workers=1)     # the native loader runs its own thread pool; this thread only overlaps it
+    try:
+        slot = 0
+        first = next_chunk(BATCH_BYTES)
+        fut = pool.submit(load, first, slot) if first else None
+        while fut is not None:
+            chunk, pinned, (info, names, used) = fut.result()
+            nxt = next_chunk(BATCH_BYTES)
+            fut = pool.submit(load, nxt, 1 - slot) if nxt else None      # ingest of the next batch overlaps this one's scan
+            bases = pinned.array
+            status = info["status"]
+            if (status == PFA_ERR_IO).any():
+                path = chunk[int(np.flatnonzero(status == PFA_ERR_IO)[0])][1]
+                open(path, "rb").close()          # raises the OSError the reference would raise (:239)
+                raise OSError(f"cannot read {path}")
+            deferred = [chunk[k] for k in np.flatnonzero(status == PFA_FILE_DEFERRED)]
+            descs, ridx, pending = [], None, []
+            if not args.pops:
+                # one unit per packed file: build the descriptor table without a Python loop
+                ok = np.flatnonzero(status == 0)
+                descs = np.zeros(len(ok), dtype=DESC_DTYPE)
+                for f in ("base_off", "n_sites", "row_stride"):
+                    descs[f] = info[f][ok]
+                descs["n_rows"] = descs["mat_rows"] = info["n_rows"][ok]
+                descs["row_idx_off"] = PFA_NO_ROW_IDX
+                descs["flags"] = PFA_FLAG_CDS if args.cds else 0
+                unit_of = dict(zip(ok.tolist(), range(len(ok))))
+                for k, fi in enumerate(info.tolist()):
+                    st = fi[0]
+                    if st == PFA_FILE_DEFERRED:
+                        continue
+                    fidx, path = chunk[k]
+                    pending += _events_for(fidx, path, path.split("/")[-1], st, None, fi[1], fi[2], args,
+                                           lambda rows, k=k: unit_of[k])
+            else:
+                dl, rl = [], []
+                for k, fi in enumerate(info):
+                    st = int(fi["status"])
+                    if st == PFA_FILE_DEFERRED:
+                        continue
+                    fidx, path = chunk[k]
+
+                    def add_unit(rows, fi=fi):
+                        d = np.zeros(1, dtype=DESC_DTYPE)[0]
+                        d["base_off"], d["n_sites"], d["row_stride"], d["mat_rows"] = fi["base_off"], fi["n_sites"], fi["row_stride"], fi["n_rows"]
+                        d["flags"] = PFA_FLAG_CDS if args.cds else 0
+                        d["n_rows"], d["row_idx_off"] = len(rows), sum(len(r) for r in rl)
+                        rl.append(np.asarray(rows, dtype=np.uint32))
+                        dl.append(d)
+                        return len(dl) - 1
+                    pending += _events_for(fidx, path, path.split("/")[-1], st, names[k], int(fi["n_rows"]),
+                                           int(fi["n_sites"]), args, add_unit)
+                descs = np.array(dl, dtype=DESC_DTYPE) if dl else []
+                ridx = np.concatenate(rl) if rl else None
+            out = _scan_table(bases, used, descs, ridx) if len(descs) else None
+            _attach(pending, out, done)
+            if deferred:
+                if len(deferred) == len(chunk):
+                    # nothing fitted: the first file alone is larger than the buffer.  Let the ingest in
+                    # flight finish, then load that file alone into a buffer grown to its size.
+                    if fut is not None:
+                        queue.extendleft(reversed(fut.result()[0]))
+                    need = (int(info[0]["row_stride"]) << 8) + (1 << 20)
+                    queue.extendleft(reversed(deferred[1:]))
+                    fut = pool.submit(load, deferred[:1], slot, need)
+                    continue
+                queue.extendleft(reversed(deferred))
+                if fut is None:
+                    nxt = next_chunk(BATCH_BYTES)
+                    fut = pool.submit(load, nxt, 1 - slot) if nxt else None
+            slot = 1 - slot
+    finally:
+        pool.shutdown(wait=True)
     done.sort(key=lambda ev: ev[0])       # stable: deferred files return to their sorted position
     return done
 

@@ -122,3 +122,27 @@ def test_pops_rows(gpu, tmp_path):
                 for a, b in zip(lines, want):
                     if a != b:
                         C.rows_close(a, b, jc=jc)
+
+
+def test_many_files_small_buffers(gpu, tmp_path, monkeypatch):
+    """Force several ingest batches, deferred files and one file larger than the
+    buffer: rows must still come out once each, in sorted-path order."""
+    import numpy as np
+    from oracle import c_oracle
+    monkeypatch.setattr(cli, "BATCH_BYTES", 1 << 20)
+    monkeypatch.setattr(cli, "_pinned_cache", [None, None])
+    rows = {}
+    p = synth.make_params(12, 0.02)
+    for i in range(40):
+        L = 30000 if i != 17 else 200000          # file 17 alone exceeds the 1 MiB buffer
+        m = synth.synth_alignment(900, i, L, p)
+        (tmp_path / f"f{i:02d}.fa").write_text(synth.to_fasta_text(synth.headers_for(12), m))
+        o = c_oracle.scan(m)
+        rows[f"f{i:02d}.fa"] = (L, o["S"])
+    rc, out = run_cli(["-d", str(tmp_path), "-s"])
+    lines = out.rstrip("\n").split("\n")
+    assert [ln.split(",")[0] for ln in lines] == sorted(rows)
+    for ln in lines:
+        f = ln.split(",")
+        assert (int(f[1]), int(f[4])) == rows[f[0]]
+    monkeypatch.setattr(cli, "_pinned_cache", [None, None])
