@@ -862,6 +862,8 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
     const uint32_t tw = pfa::tile_sites_for(lb, d.flags & PFA_FLAG_CDS);
     if (d.n_rows && d.n_sites) sum_tiles += ((uint64_t)d.n_sites + tw - 1) / tw;
   }
+  // 96 single-wave workgroups per CU measured best for the bench workload (10 tiles per chunk:
+  // 6.48 TB/s; 20 tiles 6.36, 4 tiles 6.36, 1 tile 5.43)
   const uint64_t target_blocks = (uint64_t)std::max(pfa::ctx().n_cu, 1) * 96ull;
   uint64_t tpc = std::max<uint64_t>(1, sum_tiles / target_blocks);
   tpc = std::min<uint64_t>(tpc, std::max<uint32_t>(max_tiles, 1));
