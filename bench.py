@@ -201,7 +201,8 @@ def main():
                        "parallelism": f"independent alignments sharded over {world} rank(s); one RCCL all-gather of result records"
                                       if world > 1 else "single GPU",
                        "kernel_variant": {0: "lds_dma_nt", 1: "register_staged", 2: "lds_dma_default_policy"}[args.variant],
-                       "tiles_per_chunk": plan.tiles_per_chunk, "lds_bytes_per_wave": plan.lds_bytes},
+                       "tiles_per_chunk": plan.tiles_per_chunk, "lds_bytes_per_wave": plan.lds_bytes,
+                       "rows_per_chunk": plan.rows_per_chunk},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "pfa::scan_kernel", "kernel_ms_avg": k_avg_ms,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 1
+#define PFA_ABI_VERSION 2
 
 /* error codes */
 #define PFA_OK 0
@@ -47,8 +47,11 @@ extern "C" {
 #define PFA_ERR_FORMAT (-7)     /* FASTA packer: not FASTA / unsupported byte */
 #define PFA_ERR_IO (-8)
 
-/* Rows of one scan unit must fit one LDS column tile. */
-#define PFA_MAX_ROWS 2048u
+/* Rows per scan unit.  Non-coding units are streamed in row chunks, so the bound
+ * is only what 32-bit counters hold; the rows of a coding unit (PFA_FLAG_CDS)
+ * must fit one LDS column tile. */
+#define PFA_MAX_ROWS 1048576u
+#define PFA_MAX_ROWS_CDS 2048u
 
 #define PFA_NO_ROW_IDX 0xFFFFFFFFu
 
@@ -59,9 +62,10 @@ extern "C" {
 #define PFA_WANT_VAR_BITMAP 1u /* variable-site bitmap  -> `pos` of getvarsites        */
 #define PFA_WANT_SN_BITMAP 2u  /* S / N position bitmaps -> lists of getvarCDSsites    */
 
-/* Column-tile width (sites per wavefront tile) for plans whose largest unit has
- * at most 600 rows; above that the tile narrows to 64 sites so that N rows still
- * fit LDS.  Query with pfa_tile_sites().  Bitmaps are laid out per tile. */
+/* Column-tile width (sites per wavefront tile): 256, except for plans with a
+ * coding unit whose largest unit has more than 600 rows, where the tile narrows
+ * to 64 sites so that N rows still fit LDS.  Query with pfa_tile_sites().
+ * Bitmaps are laid out per tile. */
 #define PFA_TILE_SITES 256u
 
 /* One scan unit = one alignment, or one population's row subset of an
@@ -105,12 +109,12 @@ typedef struct pfa_result {
 
 typedef struct pfa_plan pfa_plan;
 
-/* tile geometry of a plan whose largest unit has `max_rows` rows: sites per
- * tile (the same for coding and non-coding units; `cds` is ignored) and 64-bit
+/* tile geometry of a plan whose largest unit has `max_rows` rows and that holds
+ * (`cds` = 1) or does not hold (0) a coding unit: sites per tile and 64-bit
  * words per tile of every bitmap.  tile_off of unit i = sum over earlier units
- * of ceil(n_sites / pfa_tile_sites(max_rows, 0)). */
+ * of ceil(n_sites / pfa_tile_sites(max_rows, cds)). */
 uint32_t pfa_tile_sites(uint32_t max_rows, uint32_t cds);
-uint32_t pfa_var_words_per_tile(uint32_t max_rows);
+uint32_t pfa_var_words_per_tile(uint32_t max_rows, uint32_t cds);
 
 /* ---- context -------------------------------------------------------------- */
 int pfa_abi_version(void);
@@ -151,6 +155,7 @@ int pfa_plan_results_dev(pfa_plan* plan, void** d_results, size_t* bytes);
 uint32_t pfa_plan_n_tiles(const pfa_plan* plan);
 uint32_t pfa_plan_tiles_per_chunk(const pfa_plan* plan); /* launch geometry, for reports */
 uint32_t pfa_plan_lds_bytes(const pfa_plan* plan);
+uint32_t pfa_plan_rows_per_chunk(const pfa_plan* plan); /* 0: all rows of a tile at once */
 uint64_t pfa_plan_sfs_words(const pfa_plan* plan);
 void pfa_plan_destroy(pfa_plan* plan);
 

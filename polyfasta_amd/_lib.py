@@ -14,13 +14,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpfa_hip.so")
 
-PFA_ABI_VERSION = 1
+PFA_ABI_VERSION = 2
 PFA_NO_ROW_IDX = 0xFFFFFFFF
 PFA_FLAG_CDS = 1
 PFA_WANT_VAR_BITMAP = 1
 PFA_WANT_SN_BITMAP = 2
 PFA_SYN_BINS = 65
-PFA_MAX_ROWS = 2048
+PFA_MAX_ROWS = 1 << 20
+PFA_MAX_ROWS_CDS = 2048
 PFA_ERR_FORMAT = -7
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -85,7 +86,7 @@ _PROTOTYPES = {
     "pfa_upload": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     "pfa_download": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     "pfa_tile_sites": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_uint32]),
-    "pfa_var_words_per_tile": (ctypes.c_uint32, [ctypes.c_uint32]),
+    "pfa_var_words_per_tile": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_uint32]),
     "pfa_plan_create": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp, ctypes.c_size_t, ctypes.c_uint64,
                                        ctypes.c_uint32, ctypes.POINTER(_vp)]),
     "pfa_plan_run": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
@@ -95,6 +96,7 @@ _PROTOTYPES = {
     "pfa_plan_n_tiles": (ctypes.c_uint32, [_vp]),
     "pfa_plan_tiles_per_chunk": (ctypes.c_uint32, [_vp]),
     "pfa_plan_lds_bytes": (ctypes.c_uint32, [_vp]),
+    "pfa_plan_rows_per_chunk": (ctypes.c_uint32, [_vp]),
     "pfa_plan_sfs_words": (ctypes.c_uint64, [_vp]),
     "pfa_plan_destroy": (None, [_vp]),
     "pfa_scan_batch": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint32, _vp, ctypes.c_size_t,

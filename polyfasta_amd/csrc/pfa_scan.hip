@@ -84,9 +84,9 @@ PFA_HD inline LdsLayout lds_layout(uint32_t lb, uint32_t n_max, bool cds, bool r
   o.tile = 0;
   (void)rpi;
   o.list = round16(n * ww);  // exactly N rows: lanes of the last DMA instruction beyond row N-1 are masked off
-  // `list` (tier-2 site list, ww bytes) is dead once tier 2 is done: the coding pass reuses the
-  // region for its two codon lists (up to 86 entries: 96 B of u8 + 176 B of u16)
-  o.hist = o.list + (cds ? (ww > 272u ? ww : 272u) : ww);
+  // `list` (tier-2 site list, ww u16 entries: site | XOR byte << 8) is dead once tier 2 is done: the
+  // coding pass reuses the region for its two codon lists (up to 86 entries: 96 B of u8 + 176 B of u16)
+  o.hist = o.list + (cds ? (2u * ww > 272u ? 2u * ww : 272u) : 2u * ww);
   o.clist = o.list;
   o.c1list = o.list + 96u;
   o.rowmap = o.hist + round16((n / 2u) * 4u + 4u);
@@ -114,8 +114,24 @@ struct ScanArgs {
   uint32_t n_max;
   uint32_t pad;        // ablation bits (timing experiments)
   uint32_t use_rowmap; // 1 when some unit carries a row-index list
-  uint32_t pad2;
+  uint32_t rows_per_chunk;  // tall kernel: rows staged per pass (multiple of 4, 8..64)
+  uint32_t max_slots;       // tall kernel: count-table slots per tile (variable sites beyond take the column path)
+  uint32_t hist_bins;       // tall kernel: SFS bins kept in LDS (higher bins go straight to global atomics)
 };
+
+struct TallLayout {
+  uint32_t tile, list, cnt, hist, total;
+};
+
+PFA_HD inline TallLayout tall_layout(uint32_t rows_per_chunk, uint32_t max_slots, uint32_t hist_bins) {
+  TallLayout o;
+  o.tile = 0;                                   // R x 256 bytes; reused at the end of a tile for the
+  o.list = round16(rows_per_chunk * 256u);      //   256-bin column histogram (1 KiB) + its site list (256 B)
+  o.cnt = o.list + max_slots * 4u;              // list: per slot  x | d << 8 | mode << 16 | site << 24
+  o.hist = o.cnt + max_slots * 24u;             // cnt: six u32 counters per slot (two-allele mode uses two)
+  o.total = o.hist + round16(hist_bins * 4u + 4u);
+  return o;
+}
 
 // ---------------------------------------------------------------- device helpers
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -134,9 +150,11 @@ __device__ inline unsigned long long wave_sum(unsigned long long v) {
   for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// sum over the 4 lanes of a quad with DPP quad_perm moves (VALU only; __shfl_xor would go
+// through ds_bpermute and the LDS queue)
 __device__ inline uint32_t quad_sum(uint32_t v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
   return v;
 }
 __device__ inline unsigned long long quad_or(unsigned long long v) {
@@ -172,7 +190,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
 
   const LdsLayout lo = lds_layout(LB, A.n_max, HAS_CDS, A.use_rowmap != 0u);
   uint8_t* const tile8 = lds + lo.tile;
-  uint8_t* const list = lds + lo.list;
+  uint16_t* const list = reinterpret_cast<uint16_t*>(lds + lo.list);
   uint32_t* const hist = reinterpret_cast<uint32_t*>(lds + lo.hist);
   uint32_t* const rowmap = reinterpret_cast<uint32_t*>(lds + lo.rowmap);
   uint32_t* const hsite = reinterpret_cast<uint32_t*>(lds + lo.hsite);
@@ -217,11 +235,24 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       const uint32_t col = umin(site0 + 16u * c, D.row_stride - 16u);
       if constexpr (STAGE != 1) {
         // STAGE 0: default cache policy; STAGE 2: non-temporal (aux = 2), the bases are read once
-        for (uint32_t g = 0; g < n_inst; ++g) {
-          const uint32_t r = g * G::RPI + rr;
-          if (r < N) {  // EXEC-masked lanes move nothing and leave their LDS slot untouched
-            const uint8_t* src = mat + (uint64_t)(mapped ? rowmap[r] : r) * D.row_stride + col;
+        if (!mapped) {
+          // a running per-lane pointer; only the last instruction can be partial (EXEC-masked lanes
+          // move nothing and leave their LDS slot untouched)
+          const uint8_t* src = mat + (uint64_t)rr * D.row_stride + col;
+          const uint64_t step = (uint64_t)G::RPI * D.row_stride;
+          const uint32_t n_full = N / G::RPI;
+          uint32_t g = 0;
+          for (; g < n_full; ++g, src += step)
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
+          if (rr < N % G::RPI)
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
+        } else {
+          for (uint32_t g = 0; g < n_inst; ++g) {
+            const uint32_t r = g * G::RPI + rr;
+            if (r < N) {
+              const uint8_t* src = mat + (uint64_t)rowmap[r] * D.row_stride + col;
+              __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
+            }
           }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -266,7 +297,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       const uint32_t off = LB * lane + b;
       const bool pb = ((vd >> (8u * b)) & 0xFFu) != 0u && off < lim;
       const uint64_t m = __ballot(pb);
-      if (pb) list[P + mbcnt64(m)] = uint8_t(off);
+      if (pb) list[P + mbcnt64(m)] = uint16_t(off | ((vd >> (8u * b)) & 0xFFu) << 8);
       if (A.var_bm != nullptr && lane == 0u)
         A.var_bm[(uint64_t)(D.tile_off + tile) * LB + b] = m;
       P += (uint32_t)__popcll(m);
@@ -280,55 +311,76 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     __syncthreads();
 
     // ---------------- tier 2: exact allele counts of the variable sites
+    // 4 lanes per site walk its column.  Fast path: x = the byte of row 0, y = x ^ (XOR byte of
+    // the site); when every row holds x or y the site has exactly these two alleles (2 compares
+    // per byte).  Otherwise (3+ alleles, ~1 % of variable sites) the column is walked again
+    // with six counters, and any byte outside A C G T - N takes the exact generic path.
     const uint32_t slot = lane >> 2, ph = lane & 3u;
     for (uint32_t p0 = 0; p0 < P && !(A.pad & 4u); p0 += 16u) {
       const uint32_t idx = p0 + slot;
       const bool act = idx < P;
-      const uint32_t s = list[act ? idx : 0u];
+      const uint32_t ent = list[act ? idx : 0u];
+      const uint32_t s = ent & 0xFFu;
       const uint8_t* colp = tile8 + s;
-      uint32_t cA = 0, cC = 0, cG = 0, cT = 0, cGap = 0, cNn = 0;
+      const uint32_t x = colp[0], y = x ^ (ent >> 8);
+      uint32_t c1 = 0, c2 = 0;
 #pragma unroll 4
       for (uint32_t r = ph; r < N; r += 4u) {
-        const uint32_t x = colp[r * G::WW];
-        cA += (x == 'A');
-        cC += (x == 'C');
-        cG += (x == 'G');
-        cT += (x == 'T');
-        cGap += (x == '-');
-        cNn += (x == 'N');
+        const uint32_t v = colp[r * G::WW];
+        c1 += (v == x);
+        c2 += (v == y);
       }
-      cA = quad_sum(cA);
-      cC = quad_sum(cC);
-      cG = quad_sum(cG);
-      cT = quad_sum(cT);
-      cGap = quad_sum(cGap);
-      cNn = quad_sum(cNn);
-      uint32_t sumsq = cA * cA + cC * cC + cG * cG + cT * cT + cGap * cGap + cNn * cNn;
-      const uint32_t n_other = N - (cA + cC + cG + cT + cGap + cNn);
-      if (__any(act && n_other != 0u)) {
-        // exact path for any other byte value: sum over such rows i of #{j : x_j == x_i}
-        uint32_t extra = 0u;
-        if (act && n_other != 0u) {
-          for (uint32_t i = ph; i < N; i += 4u) {
-            const uint32_t xi = colp[i * G::WW];
-            const bool six = xi == 'A' || xi == 'C' || xi == 'G' || xi == 'T' || xi == '-' || xi == 'N';
-            if (!six) {
-              uint32_t cnt = 0u;
-              for (uint32_t j = 0; j < N; ++j) cnt += (colp[j * G::WW] == xi);
-              extra += cnt;
-            }
+      c1 = quad_sum(c1);
+      c2 = quad_sum(c2);
+      const bool xc = base_clean(x), yc = base_clean(y);
+      uint32_t sumsq = c1 * c1 + c2 * c2;
+      uint32_t second = (xc && yc) ? umin(c1, c2) : 0u;   // second-largest A/C/G/T count (PolyFastA.py:279-281)
+      uint32_t pres = (xc ? 1u << base_code(x) : 0u) | (yc ? 1u << base_code(y) : 0u);   // which of A, C, T, G occur
+      const bool multi = act && c1 + c2 != N;   // the same in all 4 lanes of the quad
+      if (__any(multi)) {
+        if (multi) {
+          uint32_t cA = 0, cC = 0, cG = 0, cT = 0, cGap = 0, cNn = 0;
+#pragma unroll 4
+          for (uint32_t r = ph; r < N; r += 4u) {
+            const uint32_t v = colp[r * G::WW];
+            cA += (v == 'A');
+            cC += (v == 'C');
+            cG += (v == 'G');
+            cT += (v == 'T');
+            cGap += (v == '-');
+            cNn += (v == 'N');
           }
+          cA = quad_sum(cA);
+          cC = quad_sum(cC);
+          cG = quad_sum(cG);
+          cT = quad_sum(cT);
+          cGap = quad_sum(cGap);
+          cNn = quad_sum(cNn);
+          sumsq = cA * cA + cC * cC + cG * cG + cT * cT + cGap * cGap + cNn * cNn;
+          const uint32_t n_other = N - (cA + cC + cG + cT + cGap + cNn);
+          if (n_other != 0u) {
+            // exact path for any other byte value: sum over such rows i of #{j : x_j == x_i}
+            uint32_t extra = 0u;
+            for (uint32_t i = ph; i < N; i += 4u) {
+              const uint32_t xi = colp[i * G::WW];
+              const bool six = xi == 'A' || xi == 'C' || xi == 'G' || xi == 'T' || xi == '-' || xi == 'N';
+              if (!six) {
+                uint32_t cnt = 0u;
+                for (uint32_t j = 0; j < N; ++j) cnt += (colp[j * G::WW] == xi);
+                extra += cnt;
+              }
+            }
+            sumsq += quad_sum(extra);
+          }
+          const uint32_t hi1 = umax(cA, cC), lo1 = umin(cA, cC), hi2 = umax(cG, cT), lo2 = umin(cG, cT);
+          second = umax(umin(hi1, hi2), umax(lo1, lo2));
+          pres = (cA ? 1u : 0u) | (cC ? 2u : 0u) | (cT ? 4u : 0u) | (cG ? 8u : 0u);
         }
-        sumsq += quad_sum(extra);
       }
       if (act && ph == 0u) {
         const uint32_t hs = NN - sumsq;
         acc_H += hs;
-        if (cds)  // H of the site + which of A, C, T, G occur there (bits 24-27, codon base order)
-          hsite[s] = hs | ((cA ? 1u : 0u) | (cC ? 2u : 0u) | (cT ? 4u : 0u) | (cG ? 8u : 0u)) << 24;
-        // second-largest A/C/G/T count (PolyFastA.py:279-281)
-        const uint32_t hi1 = umax(cA, cC), lo1 = umin(cA, cC), hi2 = umax(cG, cT), lo2 = umin(cG, cT);
-        const uint32_t second = umax(umin(hi1, hi2), umax(lo1, lo2));
+        if (cds) hsite[s] = hs | pres << 24;   // H of the site + which of A, C, T, G occur there (bits 24-27, codon base order)
         if (second == 0u) acc_bad += 1u;
         else atomicAdd(&hist[second - 1u], 1u);
       }
@@ -590,8 +642,321 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   }
 }
 
+
+// ---------------------------------------------------------------- the tall kernel
+// Units with many rows (non-coding).  The classic kernel keeps all N rows of a 256-site tile in
+// LDS, so its occupancy falls as N grows (6 waves per CU at N = 100, 1 at N = 600).  Here a
+// wavefront streams the rows of its tile in chunks of R <= 64 rows; LDS per wave, and with it
+// the occupancy, no longer depend on N, and N itself is unbounded.
+//   per chunk   stage R rows (LDS-DMA) -> tier 1 (AND / OR of the chunk folded into the running
+//               words) -> sites that turn variable in this chunk get a count slot, initialised
+//               with "all earlier rows held the consensus byte x" -> tier 2 counts the chunk's
+//               rows of every slotted site (4 lanes per site): in two-allele mode the rows
+//               equal to x and to y = x ^ (XOR byte when slotted); the first chunk whose rows
+//               do not all hold x or y promotes the slot to six counters (A C G T - N), seeded
+//               with the exact x / y counts of the earlier chunks
+//   per tile    H and the SFS bin of every slot; sites holding other bytes than A C G T - N
+//               in six-counter mode, and sites that found no free slot, are recounted exactly
+//               from their global column through a 256-bin LDS histogram (whole wave per
+//               site; rare)
+__device__ inline uint32_t sym6(uint32_t x) {
+  return x == 'A' ? 0u : x == 'C' ? 1u : x == 'G' ? 2u : x == 'T' ? 3u : x == '-' ? 4u : x == 'N' ? 5u : 6u;
+}
+
+template <int STAGE>
+__global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  constexpr uint32_t TW = 256u;
+  const uint32_t lane = threadIdx.x;
+  const pfa_desc D = A.descs[blockIdx.x];
+  const uint32_t N = D.n_rows, L = D.n_sites;
+  if (N == 0u || L == 0u) return;
+  const uint32_t n_tiles = (L + TW - 1u) / TW;
+  const uint32_t t0 = blockIdx.y * A.tiles_per_chunk;
+  if (t0 >= n_tiles) return;
+  const uint32_t t1 = umin(t0 + A.tiles_per_chunk, n_tiles);
+
+  const uint32_t R = A.rows_per_chunk, MAXS = A.max_slots;
+  const TallLayout lo = tall_layout(R, MAXS, A.hist_bins);
+  uint8_t* const tile8 = lds + lo.tile;
+  uint32_t* const list = reinterpret_cast<uint32_t*>(lds + lo.list);
+  uint32_t* const cnt = reinterpret_cast<uint32_t*>(lds + lo.cnt);
+  uint32_t* const hist = reinterpret_cast<uint32_t*>(lds + lo.hist);
+  uint32_t* const colhist = reinterpret_cast<uint32_t*>(tile8);   // 256 bins, end-of-tile only
+  uint8_t* const xlist = tile8 + 1024u;                           // sites for the column path
+
+  const uint32_t nbins = N / 2u, HB = umin(nbins, A.hist_bins);
+  const bool mapped = D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
+  const uint32_t* const ridx = A.row_idx + (mapped ? D.row_idx_off : 0u);
+  const bool multi = N > R;
+  for (uint32_t i = lane; i < HB; i += 64u) hist[i] = 0u;
+  // lane r holds the matrix row of the chunk's row r; the next chunk's are fetched while this one is scanned
+  uint32_t idx_cur = 0u;
+  if (mapped && lane < umin(R, N)) idx_cur = ridx[lane];
+  __syncthreads();
+
+  uint32_t acc_S = 0u, acc_bad = 0u;
+  unsigned long long acc_H = 0ull;
+  const uint8_t* const mat = A.bases + D.base_off;
+  const unsigned long long NN = (unsigned long long)N * N;
+
+  // second-largest A/C/G/T count (PolyFastA.py:279-281) -> LDS histogram, high bins to global
+  auto sfs_add = [&](uint32_t cA, uint32_t cC, uint32_t cG, uint32_t cT) {
+    const uint32_t hi1 = umax(cA, cC), lo1 = umin(cA, cC), hi2 = umax(cG, cT), lo2 = umin(cG, cT);
+    const uint32_t second = umax(umin(hi1, hi2), umax(lo1, lo2));
+    if (second == 0u) acc_bad += 1u;
+    else if (second - 1u < HB) atomicAdd(&hist[second - 1u], 1u);
+    else atomicAdd(&A.sfs[D.sfs_off + second - 1u], 1u);
+  };
+
+  for (uint32_t tile = t0; tile < t1; ++tile) {
+    const uint32_t site0 = tile * TW;
+    const uint32_t lim = umin(TW, L - site0);
+    const uint32_t c16 = lane % 16u, rr = lane / 16u;
+    const uint32_t col = umin(site0 + 16u * c16, D.row_stride - 16u);
+    uint32_t va = 0xFFFFFFFFu, vo = 0u, vd = 0u;   // running AND / OR / XOR words of the rows seen so far
+    uint32_t P = 0u, ovf = 0u;                     // variable sites so far; own sites that found no slot
+
+    for (uint32_t r0 = 0; r0 < N; r0 += R) {
+      const uint32_t Rc = umin(R, N - r0);
+      uint32_t idx_nxt = idx_cur;
+      if (mapped && multi) {
+        const uint32_t r0n = r0 + R < N ? r0 + R : 0u;
+        if (lane < umin(R, N - r0n)) idx_nxt = ridx[r0n + lane];
+      }
+      // ---------------- stage Rc rows x 256 sites
+      const uint32_t n_inst = (Rc + 3u) / 4u;
+      for (uint32_t g = 0; g < n_inst; ++g) {
+        const uint32_t r = 4u * g + rr;
+        const uint32_t row = mapped ? (uint32_t)__shfl((int)idx_cur, (int)(r & 63u)) : r0 + r;
+        if (r < Rc) {
+          const uint8_t* src = mat + (uint64_t)row * D.row_stride + col;
+          if constexpr (STAGE == 1)
+            *reinterpret_cast<uint4*>(tile8 + g * 1024u + lane * 16u) = *reinterpret_cast<const uint4*>(src);
+          else
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
+        }
+      }
+      if constexpr (STAGE != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+
+      // ---------------- tier 1 on the chunk, folded into the running words
+      uint32_t ca = 0xFFFFFFFFu, co = 0u;
+      const uint32_t x0w = reinterpret_cast<const uint32_t*>(tile8)[lane];   // first row of the chunk
+      {
+        const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile8);
+#pragma unroll 8
+        for (uint32_t r = 0; r < Rc; ++r) {
+          const uint32_t x = t32[r * 64u + lane];
+          ca &= x;
+          co |= x;
+        }
+      }
+      const uint32_t nva = va & ca, nvo = vo | co, nvd = nva ^ nvo;
+
+      // ---------------- sites that turn variable in this chunk get a count slot
+#pragma unroll
+      for (uint32_t b = 0; b < 4u; ++b) {
+        const uint32_t off = 4u * lane + b;
+        const bool now = ((nvd >> (8u * b)) & 0xFFu) != 0u && off < lim;
+        const bool was = ((vd >> (8u * b)) & 0xFFu) != 0u;
+        const bool newly = now && !was;
+        const uint64_t m = __ballot(newly);
+        if (m != 0ull) {
+          if (newly) {
+            const uint32_t slot = P + mbcnt64(m);
+            if (slot < MAXS) {
+              // x: the byte every earlier row held (the site's AND byte), or that of the very first row
+              const uint32_t xb = ((r0 ? va : x0w) >> (8u * b)) & 0xFFu;
+              list[slot] = xb | ((nvd >> (8u * b)) & 0xFFu) << 8 | off << 24;   // mode 0: two alleles
+              cnt[slot * 6u] = r0;
+              cnt[slot * 6u + 1u] = 0u;
+            } else {
+              ovf |= 1u << b;
+            }
+          }
+          P += (uint32_t)__popcll(m);
+        }
+      }
+      va = nva;
+      vo = nvo;
+      vd = nvd;
+      P = __builtin_amdgcn_readfirstlane(P);
+      const uint32_t Pc = umin(P, MAXS);
+      __syncthreads();
+
+      // ---------------- tier 2: the chunk's rows of every slotted site
+      const uint32_t slot16 = lane >> 2, ph = lane & 3u;
+      const uint32_t rows_after = r0 + Rc;
+      for (uint32_t p0 = 0; p0 < Pc; p0 += 16u) {
+        const uint32_t idx = p0 + slot16;
+        const bool act = idx < Pc;
+        const uint32_t ent = list[act ? idx : 0u];
+        const uint32_t x = ent & 0xFFu, y = x ^ ((ent >> 8) & 0xFFu), mode = (ent >> 16) & 0xFFu;
+        const uint8_t* colp = tile8 + (ent >> 24);
+        uint32_t* c6 = cnt + (act ? idx : 0u) * 6u;
+        bool need6 = act && mode == 1u;
+        if (act && mode == 0u) {   // the same in all 4 lanes of the quad
+          uint32_t c1 = 0, c2 = 0;
+#pragma unroll 4
+          for (uint32_t r = ph; r < Rc; r += 4u) {
+            const uint32_t v = colp[r * TW];
+            c1 += (v == x);
+            c2 += (v == y);
+          }
+          c1 = quad_sum(c1);
+          c2 = quad_sum(c2);
+          const uint32_t o1 = c6[0], o2 = c6[1];
+          if (o1 + o2 + c1 + c2 == rows_after) {
+            if (ph == 0u) { c6[0] = o1 + c1; c6[1] = o2 + c2; }
+          } else {
+            // a third allele in this chunk: the earlier rows held exactly o1 x's and o2 y's
+            const uint32_t sx = sym6(x), sy = sym6(y);
+            const bool odd = (o1 != 0u && sx == 6u) || (o2 != 0u && sy == 6u);
+            if (ph == 0u) {
+#pragma unroll
+              for (uint32_t k = 0; k < 6u; ++k) c6[k] = (sx == k ? o1 : 0u) + (sy == k ? o2 : 0u);
+              list[idx] = (ent & 0xFF00FFFFu) | (odd ? 2u : 1u) << 16;   // mode 2: column path at the end of the tile
+            }
+            need6 = !odd;
+          }
+        }
+        if (__any(need6)) {
+          if (need6) {
+            uint32_t cA = 0, cC = 0, cG = 0, cT = 0, cGap = 0, cNn = 0;
+#pragma unroll 4
+            for (uint32_t r = ph; r < Rc; r += 4u) {
+              const uint32_t v = colp[r * TW];
+              cA += (v == 'A');
+              cC += (v == 'C');
+              cG += (v == 'G');
+              cT += (v == 'T');
+              cGap += (v == '-');
+              cNn += (v == 'N');
+            }
+            cA = quad_sum(cA);
+            cC = quad_sum(cC);
+            cG = quad_sum(cG);
+            cT = quad_sum(cT);
+            cGap = quad_sum(cGap);
+            cNn = quad_sum(cNn);
+            if (ph == 0u) {
+              c6[0] += cA;
+              c6[1] += cC;
+              c6[2] += cG;
+              c6[3] += cT;
+              c6[4] += cGap;
+              c6[5] += cNn;
+            }
+          }
+        }
+      }
+      __syncthreads();   // the tile buffer is reused by the next chunk
+      idx_cur = idx_nxt;
+    }
+
+    // ---------------- end of tile: S, bitmap, H and SFS of the slotted sites
+#pragma unroll
+    for (uint32_t b = 0; b < 4u; ++b) {
+      const bool pb = ((vd >> (8u * b)) & 0xFFu) != 0u && 4u * lane + b < lim;
+      const uint64_t m = __ballot(pb);
+      if (A.var_bm != nullptr && lane == 0u) A.var_bm[(uint64_t)(D.tile_off + tile) * 4u + b] = m;
+      acc_S += lane == 0u ? (uint32_t)__popcll(m) : 0u;
+    }
+    const uint32_t Pc = umin(P, MAXS);
+    uint32_t X = 0u;   // sites for the column path
+    for (uint32_t base = 0; base < Pc; base += 64u) {
+      const uint32_t idx = base + lane;
+      const bool act = idx < Pc;
+      bool ex = false;
+      uint32_t ent = 0u;
+      if (act) {
+        ent = list[idx];
+        const uint32_t mode = (ent >> 16) & 0xFFu;
+        const uint32_t* c6 = cnt + idx * 6u;
+        if (mode == 0u) {           // exactly two alleles, x and y
+          const uint32_t x = ent & 0xFFu, y = x ^ ((ent >> 8) & 0xFFu);
+          const uint32_t c1 = c6[0], c2 = c6[1];
+          acc_H += NN - ((unsigned long long)c1 * c1 + (unsigned long long)c2 * c2);
+          const uint32_t second = (base_clean(x) && base_clean(y)) ? umin(c1, c2) : 0u;
+          sfs_add(second, 0u, 0u, second);
+        } else if (mode == 1u) {
+          const uint32_t cA = c6[0], cC = c6[1], cG = c6[2], cT = c6[3], cGap = c6[4], cNn = c6[5];
+          ex = cA + cC + cG + cT + cGap + cNn != N;   // some row holds another byte
+          if (!ex) {
+            const unsigned long long sq = (unsigned long long)cA * cA + (unsigned long long)cC * cC +
+                                          (unsigned long long)cG * cG + (unsigned long long)cT * cT +
+                                          (unsigned long long)cGap * cGap + (unsigned long long)cNn * cNn;
+            acc_H += NN - sq;
+            sfs_add(cA, cC, cG, cT);
+          }
+        } else {
+          ex = true;
+        }
+      }
+      const uint64_t m = __ballot(ex);
+      if (ex) xlist[X + mbcnt64(m)] = uint8_t(ent >> 24);
+      X += (uint32_t)__popcll(m);
+    }
+#pragma unroll
+    for (uint32_t b = 0; b < 4u; ++b) {
+      const bool o = (ovf >> b) & 1u;
+      const uint64_t m = __ballot(o);
+      if (o) xlist[X + mbcnt64(m)] = uint8_t(4u * lane + b);
+      X += (uint32_t)__popcll(m);
+    }
+    X = __builtin_amdgcn_readfirstlane(X);
+    __syncthreads();
+
+    // ---------------- column path: exact allele counts of one site from global memory
+    for (uint32_t i = 0; i < X; ++i) {
+      const uint32_t s = xlist[i];
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; ++k) colhist[lane + 64u * k] = 0u;
+      __syncthreads();
+      const uint8_t* gcol = mat + site0 + s;
+      for (uint32_t r = lane; r < N; r += 64u) {
+        const uint32_t row = mapped ? ridx[r] : r;
+        atomicAdd(&colhist[gcol[(uint64_t)row * D.row_stride]], 1u);
+      }
+      __syncthreads();
+      unsigned long long sq = 0ull;
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; ++k) {
+        const unsigned long long v = colhist[lane + 64u * k];
+        sq += v * v;
+      }
+      sq = wave_sum(sq);
+      if (lane == 0u) {
+        acc_H += NN - sq;
+        sfs_add(colhist['A'], colhist['C'], colhist['G'], colhist['T']);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---------------- flush the chunk's partial sums
+  pfa_result* Rz = A.results + blockIdx.x;
+  acc_S = wave_sum(acc_S);
+  acc_bad = wave_sum(acc_bad);
+  acc_H = wave_sum(acc_H);
+  if (lane == 0u) {
+    if (acc_S) atomicAdd(&Rz->seg_sites, acc_S);
+    if (acc_bad) atomicAdd(&Rz->sfs_bad, acc_bad);
+    if (acc_H) atomicAdd(reinterpret_cast<unsigned long long*>(&Rz->H), acc_H);
+  }
+  __syncthreads();
+  for (uint32_t i = lane; i < HB; i += 64u) {
+    const uint32_t v = hist[i];
+    if (v) atomicAdd(&A.sfs[D.sfs_off + i], v);
+  }
+}
+
 // ---------------------------------------------------------------- plans
-static constexpr uint32_t kMaxRowsWide = 600u;  // LB = 4 (256-site tiles) up to here, LB = 1 above
+static constexpr uint32_t kMaxRowsWide = 600u;  // coding plans: LB = 4 (256-site tiles) up to here, LB = 1 above
+static constexpr uint32_t kTallMin = 64u;       // non-coding plans with more rows than this: scan_tall_kernel
+static constexpr uint32_t kTallRows = 48u;      // its rows per chunk (upper bound)
+static constexpr uint32_t kTallSlots = 96u;     // its count-table slots per tile
 static constexpr int kEventRing = 64;
 
 }  // namespace pfa
@@ -607,6 +972,8 @@ struct pfa_plan {
   uint32_t want = 0;
   bool any_cds = false;
   bool use_rowmap = false;
+  bool tall = false;              // row-chunked kernel (non-coding plans with many-row units)
+  uint32_t rows_per_chunk = 0, max_slots = 0, hist_bins = 0;
   uint64_t sfs_words = 0;
   uint64_t n_bases_bytes = 0;
   uint32_t lds_bytes = 0;
@@ -631,7 +998,28 @@ struct pfa_plan {
 namespace pfa {
 
 static uint32_t tile_sites_for(uint32_t lb, bool /*cds*/) { return 64u * lb; }
-static uint32_t lb_for(uint32_t n_max) { return n_max <= kMaxRowsWide ? 4u : 1u; }
+// coding plans above 600 rows fall back to 64-site tiles; non-coding plans switch to the
+// row-chunked kernel long before that and always use 256-site tiles
+static uint32_t lb_for(uint32_t n_max, bool any_cds) { return (!any_cds || n_max <= kMaxRowsWide) ? 4u : 1u; }
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* e = getenv(name);
+  return e && *e ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
+}
+
+template <int STAGE>
+static int launch_tall(const pfa_plan* p, const ScanArgs& a) {
+  auto kern = scan_tall_kernel<STAGE>;
+  static uint32_t lds_limit_set = 0;
+  if (p->lds_bytes > lds_limit_set) {
+    PFA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes));
+    lds_limit_set = p->lds_bytes;
+  }
+  dim3 grid(p->n_desc, p->n_chunks, 1), block(64, 1, 1);
+  hipLaunchKernelGGL(kern, grid, block, p->lds_bytes, ctx().stream, a);
+  PFA_HIP(hipGetLastError());
+  return PFA_OK;
+}
 
 template <int LB, int STAGE, bool CDS>
 static int launch(const pfa_plan* p, const ScanArgs& a) {
@@ -749,10 +1137,10 @@ int pfa_download(void* dst_host, const void* src_dev, size_t bytes) {
 }
 
 uint32_t pfa_tile_sites(uint32_t max_rows, uint32_t cds) {
-  return pfa::tile_sites_for(pfa::lb_for(max_rows), cds != 0);
+  return pfa::tile_sites_for(pfa::lb_for(max_rows, cds != 0), cds != 0);
 }
 
-uint32_t pfa_var_words_per_tile(uint32_t max_rows) { return pfa::lb_for(max_rows); }
+uint32_t pfa_var_words_per_tile(uint32_t max_rows, uint32_t cds) { return pfa::lb_for(max_rows, cds != 0); }
 
 void pfa_plan_destroy(pfa_plan* p) {
   if (!p) return;
@@ -785,11 +1173,15 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
     n_max = std::max(n_max, descs[i].n_rows);
     any_cds = any_cds || (descs[i].flags & PFA_FLAG_CDS);
   }
-  if (n_max > PFA_MAX_ROWS) {
-    pfa::set_error("a scan unit has %u rows; at most %u fit one LDS column tile", n_max, PFA_MAX_ROWS);
+  if (any_cds && n_max > PFA_MAX_ROWS_CDS) {
+    pfa::set_error("a coding scan unit has %u rows; at most %u fit one LDS column tile", n_max, PFA_MAX_ROWS_CDS);
     return PFA_ERR_TOO_MANY_ROWS;
   }
-  const uint32_t lb = pfa::lb_for(n_max);
+  if (n_max > PFA_MAX_ROWS) {
+    pfa::set_error("a scan unit has %u rows; the limit is %u", n_max, PFA_MAX_ROWS);
+    return PFA_ERR_TOO_MANY_ROWS;
+  }
+  const uint32_t lb = pfa::lb_for(n_max, any_cds);
   uint64_t sfs_words = 0, tiles_total = 0;
   uint32_t max_tiles = 0;
   for (uint32_t i = 0; i < n_desc; ++i) {
@@ -853,6 +1245,18 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
   p->n_bases_bytes = n_bases_bytes;
   p->use_rowmap = n_row_idx != 0;
   p->lds_bytes = pfa::lds_layout(lb, n_max, any_cds, p->use_rowmap).total;
+  // Non-coding plans whose largest unit exceeds kTallMin rows run the row-chunked kernel:
+  // equal chunks of at most kTallRows rows (a multiple of 4: one LDS-DMA instruction moves 4 rows).
+  // PFA_TALL_* environment overrides exist for timing experiments.
+  if (!any_cds && n_max > pfa::env_u32("PFA_TALL_MIN", pfa::kTallMin)) {
+    const uint32_t rcap = std::min(64u, std::max(8u, pfa::env_u32("PFA_TALL_ROWS", pfa::kTallRows)));
+    const uint32_t nc = (n_max + rcap - 1u) / rcap;
+    p->tall = true;
+    p->rows_per_chunk = std::min(64u, std::max(8u, ((n_max + nc - 1u) / nc + 3u) & ~3u));
+    p->max_slots = std::min(256u, std::max(16u, pfa::env_u32("PFA_TALL_SLOTS", pfa::kTallSlots)));
+    p->hist_bins = std::min(n_max / 2u, 256u);
+    p->lds_bytes = pfa::tall_layout(p->rows_per_chunk, p->max_slots, p->hist_bins).total;
+  }
 
   // chunking: enough single-wave workgroups to fill 256 CUs several times over,
   // but whole alignments per wave once the batch is large (fewer atomics)
@@ -946,7 +1350,9 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   a.tiles_per_chunk = p->tiles_per_chunk;
   a.n_max = p->n_max;
   a.use_rowmap = p->use_rowmap ? 1u : 0u;
-  a.pad2 = 0;
+  a.rows_per_chunk = p->rows_per_chunk;
+  a.max_slots = p->max_slots;
+  a.hist_bins = p->hist_bins;
   { const char* e = getenv("PFA_ABLATE"); a.pad = e ? (uint32_t)atoi(e) : 0u; }  // timing experiments only
 
   const int slot = (int)(p->n_runs % pfa::kEventRing);
@@ -957,8 +1363,10 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
 #define PFA_LAUNCH(LB, CDS)                                            \
   (stage == 0 ? pfa::launch<LB, 0, CDS>(p, a)                          \
               : stage == 1 ? pfa::launch<LB, 1, CDS>(p, a) : pfa::launch<LB, 2, CDS>(p, a))
-  if (p->lb == 4) rc = p->any_cds ? PFA_LAUNCH(4, true) : PFA_LAUNCH(4, false);
-  else            rc = p->any_cds ? PFA_LAUNCH(1, true) : PFA_LAUNCH(1, false);
+  if (p->tall)
+    rc = stage == 0 ? pfa::launch_tall<0>(p, a) : stage == 1 ? pfa::launch_tall<1>(p, a) : pfa::launch_tall<2>(p, a);
+  else if (p->lb == 4) rc = p->any_cds ? PFA_LAUNCH(4, true) : PFA_LAUNCH(4, false);
+  else                 rc = p->any_cds ? PFA_LAUNCH(1, true) : PFA_LAUNCH(1, false);
 #undef PFA_LAUNCH
   if (rc != PFA_OK) return rc;
   PFA_HIP(hipEventRecord(p->ev1[slot], st));
@@ -1021,6 +1429,7 @@ uint32_t pfa_plan_n_tiles(const pfa_plan* p) { return p ? p->n_tiles_total : 0u;
 uint64_t pfa_plan_sfs_words(const pfa_plan* p) { return p ? p->sfs_words : 0ull; }
 uint32_t pfa_plan_tiles_per_chunk(const pfa_plan* p) { return p ? p->tiles_per_chunk : 0u; }
 uint32_t pfa_plan_lds_bytes(const pfa_plan* p) { return p ? p->lds_bytes : 0u; }
+uint32_t pfa_plan_rows_per_chunk(const pfa_plan* p) { return p ? p->rows_per_chunk : 0u; }
 
 int pfa_scan_batch(const uint8_t* bases, uint64_t n_bases_bytes, const pfa_desc* descs,
                    uint32_t n_desc, const uint32_t* row_idx, size_t n_row_idx,

@@ -80,7 +80,8 @@ def finalize_layout(descs: np.ndarray, row_idx, n_bases_bytes: int) -> UnitTable
     lib = _lib.load()
     descs = np.ascontiguousarray(descs, dtype=DESC_DTYPE)
     n_max = int(descs["n_rows"].max()) if len(descs) else 0
-    tw = int(lib.pfa_tile_sites(n_max, 0))
+    any_cds = int(bool(len(descs)) and bool(((descs["flags"] & PFA_FLAG_CDS) != 0).any()))
+    tw = int(lib.pfa_tile_sites(n_max, any_cds))
     width = np.int64(tw)
     live = (descs["n_rows"] > 0) & (descs["n_sites"] > 0)
     n_tiles = np.where(live, (descs["n_sites"].astype(np.int64) + width - 1) // width, 0)
@@ -89,7 +90,7 @@ def finalize_layout(descs: np.ndarray, row_idx, n_bases_bytes: int) -> UnitTable
     descs["tile_off"] = np.concatenate(([0], np.cumsum(n_tiles)[:-1])) if len(descs) else 0
     ri = np.ascontiguousarray(row_idx if row_idx is not None else np.zeros(0), dtype=np.uint32)
     return UnitTable(descs=descs, row_idx=ri, n_bases_bytes=int(n_bases_bytes), n_max=n_max,
-                     tile_sites=tw, var_words=int(lib.pfa_var_words_per_tile(n_max)), n_tiles=n_tiles)
+                     tile_sites=tw, var_words=int(lib.pfa_var_words_per_tile(n_max, any_cds)), n_tiles=n_tiles)
 
 
 class Batch:
@@ -244,6 +245,11 @@ class Plan:
     @property
     def lds_bytes(self) -> int:
         return int(_lib.load().pfa_plan_lds_bytes(self.handle))
+
+    @property
+    def rows_per_chunk(self) -> int:
+        """rows staged per pass by the row-chunked kernel (0: the whole tile at once)"""
+        return int(_lib.load().pfa_plan_rows_per_chunk(self.handle))
 
     def close(self):
         if self.handle is not None and self.handle.value:

@@ -64,7 +64,7 @@ def test_random_batches(gpu, seed):
 
 
 def test_random_many_rows(gpu):
-    """plans whose largest unit has more than 600 rows run the 64-site-tile kernel for every unit"""
+    """coding plans whose largest unit has more than 600 rows run the 64-site-tile kernel for every unit"""
     rng = np.random.default_rng(99)
     b = scan.Batch()
     units = []
@@ -79,8 +79,68 @@ def test_random_many_rows(gpu):
         _compare(out, i, c_oracle.scan(m, rows=rows, cds=cds, want_sites=True), cds)
 
 
+def _tall_batch(rng, shapes, p_muts, subsets=True):
+    b = scan.Batch(stride_align=int(rng.choice([16, 128])))
+    units = []
+    for n, L in shapes:
+        alpha = ALPHABETS[int(rng.integers(0, len(ALPHABETS)))]
+        m = _random_matrix(rng, n, L, alpha, float(rng.choice(p_muts)))
+        mid = b.add_matrix(m)
+        b.add_unit(mid)
+        units.append((m, None, False))
+        if subsets and n >= 3:
+            rows = rng.permutation(n)[: int(rng.integers(1, n + 1))].astype(np.uint32)
+            b.add_unit(mid, rows=rows)
+            units.append((m, rows, False))
+    return b, units
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_tall_units(gpu, seed):
+    """non-coding plans whose largest unit has more than 64 rows run the row-chunked kernel for
+    every unit: chunk boundaries, sites that turn variable in a late chunk, odd symbols and
+    slot overflow (column path), row subsets in any order, rows beyond the old 2 048 limit"""
+    rng = np.random.default_rng(4321 + seed)
+    big = [(3000, 300), (5000, 70)][seed % 2]
+    shapes = [(int(rng.choice([65, 66, 96, 97, 100, 127, 128, 129, 191, 200, 255, 256, 300, 700])),
+               int(rng.choice([1, 3, 16, 255, 256, 257, 513, 1000, 3001]))) for _ in range(24)]
+    shapes += [(1, 40), (2, 300), (50, 1000), big]
+    b, units = _tall_batch(rng, shapes, [0.0, 0.0005, 0.01, 0.05, 0.5])
+    bases, table = b.pack()
+    plan = scan.Plan(table, want_pos=True)
+    assert plan.rows_per_chunk > 0          # the row-chunked kernel was selected
+    plan.close()
+    out = scan.scan_batch(b, want_pos=True)
+    for i, (m, rows, cds) in enumerate(units):
+        _compare(out, i, c_oracle.scan(m, rows=rows, want_sites=True), False)
+
+
+@pytest.mark.parametrize("rows_per_chunk,slots", [(8, 16), (12, 256), (64, 96)])
+def test_tall_kernel_forced_on_small_units(gpu, monkeypatch, rows_per_chunk, slots):
+    """the same kernel forced onto units of any size (timing-experiment overrides), tiny chunks
+    and a tiny slot table: many chunks per tile and frequent slot overflow"""
+    monkeypatch.setenv("PFA_TALL_MIN", "0")
+    monkeypatch.setenv("PFA_TALL_ROWS", str(rows_per_chunk))
+    monkeypatch.setenv("PFA_TALL_SLOTS", str(slots))
+    rng = np.random.default_rng(7 + rows_per_chunk)
+    shapes = [(int(rng.choice([1, 2, 3, 7, 8, 9, 16, 17, 31, 33, 50, 64, 65, 100, 130])),
+               int(rng.choice([1, 5, 64, 255, 256, 257, 770, 1537]))) for _ in range(40)]
+    b, units = _tall_batch(rng, shapes, [0.0, 0.002, 0.02, 0.3])
+    plan = scan.Plan(b.pack()[1])
+    assert 0 < plan.rows_per_chunk <= max(rows_per_chunk, 8)
+    plan.close()
+    out = scan.scan_batch(b, want_pos=True)
+    for i, (m, rows, cds) in enumerate(units):
+        _compare(out, i, c_oracle.scan(m, rows=rows, want_sites=True), False)
+
+
 def test_too_many_rows_is_refused(gpu):
+    """coding units must fit one LDS column tile; non-coding units are streamed in row chunks"""
     from polyfasta_amd import _lib
+    m = np.full((2049, 32), 65, dtype=np.uint8)
     with pytest.raises(_lib.PfaError) as e:
-        scan.scan_matrix(np.full((2049, 32), 65, dtype=np.uint8))
+        scan.scan_matrix(m, cds=True)
     assert e.value.code == -5
+    m[7, 3] = 67
+    r = scan.scan_matrix(m).results[0]
+    assert (int(r["seg_sites"]), int(r["H"])) == (1, 2049 * 2049 - 2048 * 2048 - 1)

@@ -13,7 +13,7 @@ import csv, glob, collections
 f = glob.glob("$OUT/sq/*/*_counter_collection.csv")[0]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if "scan_kernel" in r["Kernel_Name"]:
+    if "scan_" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]:
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 w = sum(agg["SQ_WAVE_CYCLES"]) / len(agg["SQ_WAVE_CYCLES"])
 for k, v in sorted(agg.items()):
