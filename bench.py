@@ -89,7 +89,7 @@ def measured_traffic(cfg):
             continue
         w = j.get("workload", {})
         if all(w.get(k) == cfg.get(k) for k in ("rows", "sites", "batch_per_gpu", "row_stride", "kernel_variant")) \
-                and ("coding" in w.get("workload", "")) == ("coding" in cfg.get("workload", "")):
+                and all((k in w.get("workload", "")) == (k in cfg.get("workload", "")) for k in ("coding", "populations")):
             best = j.get("traffic_bytes_per_launch")
     return best
 
@@ -205,7 +205,7 @@ def main():
                        "rows_per_chunk": plan.rows_per_chunk},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "pfa::scan_kernel", "kernel_ms_avg": k_avg_ms,
+                         "kernel": "pfa::scan_tall_kernel" if plan.rows_per_chunk else "pfa::scan_kernel", "kernel_ms_avg": k_avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "frac_of_measured_copy_6290": achieved / 6290.0},
             "timing_ms": {"enqueue": t_enq * 1e3, "until_kernels_done": t_run * 1e3, "fetch": t_fetch * 1e3,

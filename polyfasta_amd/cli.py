@@ -48,33 +48,51 @@ def _ingest_buffer(slot, min_bytes=0):
     return _pinned_cache[slot]
 
 
+# field order of pfa_result / RESULT_DTYPE
+_H, _HS, _HN, _SEG, _BAD, _SEGS, _SEGN, _STOPS, _MISSING = range(9)
+
+
+def _fields(res):
+    """A device record as a tuple of Python ints (numpy records convert here; the batch
+    path converts whole result arrays at once)."""
+    return res if isinstance(res, tuple) else res.tolist()
+
+
 def format_plain_row(name, pop, n_rows, seqlen, res, jc):
     """One non-coding CSV row from a device record (PolyFastA.py:182-198)."""
-    s = int(res["seg_sites"])
+    r = _fields(res)
+    s = r[_SEG]
     if s == 0:
         return f"{name},{seqlen},{pop},{n_rows},{NO_VAR}"
-    p = stats.finish_polymorphism(s, int(res["H"]), n_rows, seqlen, jc)
+    p = stats.finish_polymorphism(s, r[_H], n_rows, seqlen, jc)
     return f"{name},{seqlen},{pop},{n_rows},{p[0]},{p[1]},{p[2]},{p[3]}"
 
 
 def format_cds_row(name, pop, n_rows, seqlen, res, syn_num, jc):
     """One coding CSV row (PolyFastA.py:151-180), including the reference's
     mis-ordered no-variation row (:160-162)."""
+    r = _fields(res)
     ssites = stats.syn_sites_from_bins(syn_num)
-    nsites = (seqlen - 3 * int(res["missing_cols"])) - ssites
-    if int(res["seg_sites"]) == 0:
+    nsites = (seqlen - 3 * r[_MISSING]) - ssites
+    if r[_SEG] == 0:
         return f"{name},{round(ssites, 2)},{round(nsites, 2)},{pop},{n_rows},{NO_VAR},{NO_VAR},{0}"
-    ps = stats.finish_polymorphism(int(res["seg_S"]), int(res["H_S"]), n_rows, ssites, jc)
-    pn = stats.finish_polymorphism(int(res["seg_N"]), int(res["H_N"]), n_rows, nsites, jc)
+    ps = stats.finish_polymorphism(r[_SEGS], r[_HS], n_rows, ssites, jc)
+    pn = stats.finish_polymorphism(r[_SEGN], r[_HN], n_rows, nsites, jc)
     return (f"{name},{round(ssites, 2)},{round(nsites, 2)},{pop},{n_rows},{ps[0]},{pn[0]},{ps[1]},{pn[1]},"
-            f"{ps[2]},{pn[2]},{ps[3]},{pn[3]},{int(res['nstops'])}")
+            f"{ps[2]},{pn[2]},{ps[3]},{pn[3]},{r[_STOPS]}")
 
 
 class Sink:
-    """stdout, or append-to-file with the reference's progress chatter."""
+    """stdout, or append-to-file with the reference's progress chatter.  The reference
+    re-opens the output file in append mode for every line (PolyFastA.py:156,175,185,193);
+    here the lines are collected and appended in large writes, which leaves the same
+    file behind at 100 k rows without 100 k opens."""
+
+    FLUSH_LINES = 8192
 
     def __init__(self, out, silent):
         self.out, self.silent = out, silent
+        self._pending = []
 
     def header(self, cds):
         if self.silent:
@@ -86,19 +104,28 @@ class Sink:
         else:
             print(text)
 
+    def _write(self, text):
+        self._pending.append(text)
+        if len(self._pending) >= self.FLUSH_LINES:
+            self.flush()
+
+    def flush(self):
+        if self.out and self._pending:
+            with open(self.out, "a") as o:
+                o.write("\n".join(self._pending) + "\n")
+        self._pending = []
+
     def comment(self, text):
         if self.out:
-            with open(self.out, "a") as o:
-                o.write(text + "\n")
+            self._write(text)
         else:
             print(text)
 
     def row(self, text, name, pop):
         if self.out:
-            with open(self.out, "a") as o:
-                if not self.silent:
-                    print("\r", f"Writting to {self.out}, pop: {pop:<10s}, parsing: {name:<15s}", end="", flush=True)
-                o.write(text + "\n")
+            if not self.silent:
+                print("\r", f"Writting to {self.out}, pop: {pop:<10s}, parsing: {name:<15s}", end="", flush=True)
+            self._write(text)
         else:
             print(text)
 
@@ -166,11 +193,12 @@ def _events_for(fidx, path, name, status, names, n_rows, seqlen, args, add_unit)
 
 
 def _attach(pending, out, done):
+    recs = out.results.tolist() if out is not None else None     # tuples of Python ints, one conversion per batch
     for ev in pending:
         if ev[1] == "unit":
             fidx, _, unit, name, pop, n_rows, seqlen = ev
-            syn = out.syn_num[unit].copy() if out.syn_num is not None else None
-            done.append((fidx, "unit", name, pop, n_rows, seqlen, out.results[unit].copy(), syn))
+            syn = out.syn_num[unit] if out.syn_num is not None else None
+            done.append((fidx, "unit", name, pop, n_rows, seqlen, recs[unit], syn))
         else:
             done.append(ev)
 
@@ -304,6 +332,7 @@ def emit(events, sink, cds, jc):
             text = (format_cds_row(name, pop, n_rows, seqlen, res, syn, jc) if cds
                     else format_plain_row(name, pop, n_rows, seqlen, res, jc))
             sink.row(text, name, pop)
+    sink.flush()
 
 
 def gather_events(group, events):
@@ -314,8 +343,9 @@ def gather_events(group, events):
     units = [ev for ev in events if ev[1] == "unit"]
     rec = np.zeros(len(units), dtype=RESULT_DTYPE)
     syn = np.zeros((len(units), PFA_SYN_BINS), dtype=np.uint32)
+    if units:
+        rec[:] = np.array([_fields(ev[6]) for ev in units], dtype=RESULT_DTYPE)
     for i, ev in enumerate(units):
-        rec[i] = ev[6]
         if ev[7] is not None:
             syn[i] = ev[7]
     all_rec = group.all_gather_records(rec)
@@ -328,9 +358,10 @@ def gather_events(group, events):
     for r in range(group.world):
         k = 0
         syn_r = all_syn[r].reshape(-1, PFA_SYN_BINS)
+        rec_r = all_rec[r].tolist()
         for seq, ev in enumerate(all_meta[r]):
             if ev[1] == "unit":
-                merged.append((ev[0], r, seq, ev + (all_rec[r][k], syn_r[k])))
+                merged.append((ev[0], r, seq, ev + (rec_r[k], syn_r[k])))
                 k += 1
             else:
                 merged.append((ev[0], r, seq, ev))

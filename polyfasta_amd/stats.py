@@ -40,16 +40,23 @@ def pi_total(h: int, n: int) -> float:
     return h / (n * (n - 1))
 
 
-def tajima_sd(seg_sites: int, n: int) -> float:
-    """PolyFastA.py:522-534 with the reference's operand order."""
+@lru_cache(maxsize=None)
+def tajima_e(n: int):
+    """(e1, e2) of PolyFastA.py:522-533 with the reference's operand order (they depend on n only)."""
     a1, a2 = harmonic_terms(n)
-    ss = seg_sites
     b1 = (n + 1.0) / (3.0 * (n - 1.0))
     b2 = (2.0 * ((n ** 2.0) + n + 3.0)) / (9.0 * n * (n - 1.0))
     c1 = b1 - (1 / a1)
     c2 = b2 - ((n + 2) / (a1 * n)) + (a2 / (a1 ** 2))
     e1 = c1 / a1
     e2 = c2 / ((a1 ** 2) + a2)
+    return e1, e2
+
+
+def tajima_sd(seg_sites: int, n: int) -> float:
+    """PolyFastA.py:534."""
+    e1, e2 = tajima_e(n)
+    ss = seg_sites
     return math.sqrt((e1 * ss) + (e2 * ss * (ss - 1)))
 
 
@@ -84,9 +91,10 @@ def syn_sites_from_bins(syn_num) -> float:
     """Synonymous-site count of PolyFastA.py:307 from the device's integer bins:
     sum over k of (sum of synonymous-neighbour counts of columns with k distinct
     clean codons) / (3 k)."""
+    import numpy as np
+    bins = np.asarray(syn_num)
     total = 0.0
-    for k in range(1, len(syn_num)):
-        v = int(syn_num[k])
-        if v:
-            total += v / (3.0 * k)
+    for k in np.flatnonzero(bins).tolist():      # ascending k: the summation order is part of the result
+        if k:
+            total += int(bins[k]) / (3.0 * k)
     return total

@@ -47,7 +47,7 @@ def main():
         for a, b in zip(merged, want):
             ok = ok and a[:6] == b[:6]
             if a[1] == "unit":
-                ok = ok and a[6] == b[6] and (a[7] == b[7]).all()
+                ok = ok and tuple(a[6]) == tuple(b[6].tolist()) and (a[7] == b[7]).all()
         json.dump({"ok": bool(ok), "n": len(merged), "world": g.world, "tmax": tmax}, open(out_path, "w"))
     g.close()
 

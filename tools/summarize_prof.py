@@ -24,14 +24,14 @@ shutil.copyfile(stats, os.path.join(dst, f"{name}_kernel_stats.csv"))
 def counter(kind, cname):
     f = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if r["Counter_Name"] == cname and "scan_kernel" in r["Kernel_Name"]]
+            if r["Counter_Name"] == cname and "pfa::scan_" in r["Kernel_Name"]]
     return vals
 
 
 fetch = counter("pmc_fetch", "FETCH_SIZE")
 write = counter("pmc_write", "WRITE_SIZE")
 bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
-kstat = [r for r in csv.DictReader(open(stats)) if "scan_kernel" in r["Name"]][0]
+kstat = [r for r in csv.DictReader(open(stats)) if "pfa::scan_" in r["Name"]][0]
 fetch_kb, write_kb = sum(fetch) / len(fetch), sum(write) / len(write)
 traffic = 2.0 * fetch_kb * 1024 + write_kb * 1024
 summary = {
