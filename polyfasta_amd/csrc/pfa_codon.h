@@ -192,8 +192,8 @@ constexpr Tables make_tables() {
 }  // namespace ct
 
 // ---- run-time helpers ---------------------------------------------------------
-PFA_HD inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
-PFA_HD inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }  // x != 0
+PFA_HD constexpr inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
+PFA_HD constexpr inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }  // x != 0
 
 // 2-bit code of an ASCII base and whether the byte is exactly A, C, G or T
 PFA_HD inline uint32_t base_code(uint32_t x) { return (x >> 1) & 3u; }
@@ -206,7 +206,7 @@ PFA_HD inline bool base_clean(uint32_t x) {
 // (PolyFastA.py:331-434).  `T` is the table block (host copy or device copy);
 // `info` = T.annot_info or a faster copy of it (the kernels keep one in LDS, so
 // that the common cases touch no global memory).
-PFA_HD inline uint32_t classify_sense_mask(uint64_t ms, const ct::Tables& T, const uint8_t* info) {
+PFA_HD constexpr inline uint32_t classify_sense_mask(uint64_t ms, const ct::Tables& T, const uint8_t* info) {
   const int k = popc64(ms);
   if (k < 2) return 0;                                            // PolyFastA.py:333
   if (k == 2) {
@@ -233,7 +233,7 @@ PFA_HD inline uint32_t classify_sense_mask(uint64_t ms, const ct::Tables& T, con
     bm2 |= 1u << (c & 3);
     const uint32_t id = info[c] & 0x1Fu;
     const uint32_t sh = (id & 15u) * 4u;
-    uint32_t v;
+    uint32_t v = 0;
     if (id < 16u) { lo += 1ull << sh; v = uint32_t(lo >> sh) & 15u; }
     else          { hi += 1ull << sh; v = uint32_t(hi >> sh) & 15u; }
     maxmult = v > maxmult ? v : maxmult;
@@ -249,9 +249,41 @@ PFA_HD inline uint32_t classify_sense_mask(uint64_t ms, const ct::Tables& T, con
 }
 
 // sum over the codons of a set of their synonymous-neighbour counts
-PFA_HD inline uint32_t syn_thirds_of_mask(uint64_t m, const ct::Tables& T) {
+PFA_HD constexpr inline uint32_t syn_thirds_of_mask(uint64_t m, const ct::Tables& T) {
   return popc64(m & T.t_mask[1]) + 2 * popc64(m & T.t_mask[2]) + 3 * popc64(m & T.t_mask[3]) +
          4 * popc64(m & T.t_mask[4]);
+}
+
+
+// ---- codon columns with ONE variable position ----------------------------------
+// Their codon set is the consensus codon with each A/C/G/T allele of that position
+// substituted, so everything the scan needs is a function of (position p, the two fixed
+// bases, the 4-bit allele mask): entry [(p * 16 + b4) * 16 + am], b4 = the two fixed 2-bit
+// codes in codon order, holds  synonymous-neighbour sum (bits 0-4) | stop << 5 |
+// position called synonymous << 6 | non-synonymous << 7.  Generated by running the general
+// classifier above on every such set (PolyFastA.py:301-315,319-434).
+struct SingleLut {
+  uint8_t v[3 * 16 * 16];
+};
+constexpr SingleLut make_single_lut() {
+  const ct::Tables T = ct::make_tables();
+  SingleLut o{};
+  for (uint32_t p = 0; p < 3; ++p)
+    for (uint32_t b4 = 0; b4 < 16; ++b4)
+      for (uint32_t am = 0; am < 16; ++am) {
+        const uint32_t sh = 4u - 2u * p;
+        const uint32_t hi = b4 >> 2, lo = b4 & 3u;
+        const uint32_t base = p == 0 ? (hi << 2 | lo) : p == 1 ? (hi << 4 | lo) : (hi << 4 | lo << 2);
+        uint64_t m = 0;
+        for (uint32_t e = 0; e < 4; ++e)
+          if ((am >> e) & 1u) m |= 1ull << (base | (e << sh));
+        const uint64_t ms = m & ~T.stop_mask;
+        const uint32_t labels = popc64(ms) >= 2 ? classify_sense_mask(ms, T, T.annot_info) : 0u;
+        o.v[(p * 16u + b4) * 16u + am] =
+            uint8_t(syn_thirds_of_mask(m, T) | ((m & T.stop_mask) ? 0x20u : 0u) |
+                    (((labels >> p) & 1u) << 6) | (((labels >> (3u + p)) & 1u) << 7));
+      }
+  return o;
 }
 
 }  // namespace pfa

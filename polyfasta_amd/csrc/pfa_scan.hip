@@ -58,6 +58,7 @@ static constexpr ct::Tables kHostTables = ct::make_tables();
 }  // namespace pfa
 
 __constant__ pfa::ct::Tables d_tables = pfa::ct::make_tables();
+__constant__ pfa::SingleLut d_single_lut = pfa::make_single_lut();
 
 namespace pfa {
 
@@ -72,7 +73,7 @@ struct Geo {
 };
 
 struct LdsLayout {
-  uint32_t tile, list, hist, rowmap, hsite, clist, c1list, carry, cinfo, ainfo, synhist, total;
+  uint32_t tile, list, hist, rowmap, hsite, carry, cinfo, ainfo, slut, synhist, total;
 };
 
 PFA_HD inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -84,17 +85,16 @@ PFA_HD inline LdsLayout lds_layout(uint32_t lb, uint32_t n_max, bool cds, bool r
   o.tile = 0;
   (void)rpi;
   o.list = round16(n * ww);  // exactly N rows: lanes of the last DMA instruction beyond row N-1 are masked off
-  // `list` (tier-2 site list, ww u16 entries: site | XOR byte << 8) is dead once tier 2 is done: the
-  // coding pass reuses the region for its two codon lists (up to 86 entries: 96 B of u8 + 176 B of u16)
-  o.hist = o.list + (cds ? (2u * ww > 272u ? 2u * ww : 272u) : 2u * ww);
-  o.clist = o.list;
-  o.c1list = o.list + 96u;
+  o.hist = o.list + 2u * ww;   // list: the tile's variable sites, ww u16 entries (site | XOR byte << 8)
   o.rowmap = o.hist + round16((n / 2u) * 4u + 4u);
-  o.hsite = o.rowmap + (rowmap ? round16(n * 4u) : 0u) + (cds ? 16u : 0u);  // hsite[-2], hsite[-1]: last two sites of the previous tile
+  // hsite[s]: H | allele mask << 24 of variable site s (written by tier 2; entries of other sites are stale
+  // and never used); hsite[-2], hsite[-1]: the last two sites of the previous tile
+  o.hsite = o.rowmap + (rowmap ? round16(n * 4u) : 0u) + (cds ? 16u : 0u);
   o.carry = o.hsite + (cds ? ww * 4u : 0u);
   o.cinfo = o.carry + (cds ? round16(2u * n) : 0u);   // carry: last two columns of the previous tile, per row
   o.ainfo = o.cinfo + (cds ? 64u : 0u);     // cinfo: per codon, synonymous-neighbour count | stop << 7
-  o.synhist = o.ainfo + (cds ? 64u : 0u);   // ainfo: LDS copy of Tables::annot_info
+  o.slut = o.ainfo + (cds ? 64u : 0u);      // ainfo: LDS copy of Tables::annot_info
+  o.synhist = o.slut + (cds ? (uint32_t)sizeof(SingleLut) : 0u);   // slut: LDS copy of the single-position table
   o.total = o.synhist + (cds ? round16(PFA_SYN_BINS * 4u) : 0u);
   return o;
 }
@@ -112,7 +112,7 @@ struct ScanArgs {
   uint32_t n_desc;
   uint32_t tiles_per_chunk;
   uint32_t n_max;
-  uint32_t pad;        // ablation bits (timing experiments)
+  uint32_t pad;
   uint32_t use_rowmap; // 1 when some unit carries a row-index list
   uint32_t rows_per_chunk;  // tall kernel: rows staged per pass (multiple of 4, 8..64)
   uint32_t max_slots;       // tall kernel: count-table slots per tile (variable sites beyond take the column path)
@@ -157,10 +157,22 @@ __device__ inline uint32_t quad_sum(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
   return v;
 }
-__device__ inline unsigned long long quad_or(unsigned long long v) {
-  v |= __shfl_xor(v, 1);
-  v |= __shfl_xor(v, 2);
-  return v;
+// value of the previous lane (lane 0: 0): one DPP move instead of a ds_bpermute
+__device__ inline uint32_t wave_shr1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);   // wave_shr:1
+}
+// OR over the 64 lanes with DPP moves only; the result is wave-uniform (an SGPR pair)
+__device__ inline uint32_t wave_or_uniform(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);   // row_mirror
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ inline unsigned long long wave_or_uniform(unsigned long long v) {
+  return (unsigned long long)wave_or_uniform((uint32_t)v) | (unsigned long long)wave_or_uniform((uint32_t)(v >> 32)) << 32;
 }
 __device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ inline uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -172,7 +184,9 @@ __device__ inline int codon_of(uint32_t x0, uint32_t x1, uint32_t x2) {
 }
 
 // ---------------------------------------------------------------- the kernel
-template <int LB, int STAGE, bool HAS_CDS>
+// LEAN: the plan has no row-index list and wants no per-site bitmap (the batch path of the CLI
+// and the bench): those branches, and the scalar registers they pin, are compiled out.
+template <int LB, int STAGE, bool HAS_CDS, bool LEAN>
 __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   using G = Geo<LB>;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -194,15 +208,14 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   uint32_t* const hist = reinterpret_cast<uint32_t*>(lds + lo.hist);
   uint32_t* const rowmap = reinterpret_cast<uint32_t*>(lds + lo.rowmap);
   uint32_t* const hsite = reinterpret_cast<uint32_t*>(lds + lo.hsite);
-  uint8_t* const clist = lds + lo.clist;
-  uint16_t* const c1list = reinterpret_cast<uint16_t*>(lds + lo.c1list);
   uint8_t* const carry = lds + lo.carry;
   uint8_t* const cinfo = lds + lo.cinfo;
   uint8_t* const ainfo = lds + lo.ainfo;
+  uint8_t* const slut = lds + lo.slut;
   uint32_t* const synhist = reinterpret_cast<uint32_t*>(lds + lo.synhist);
 
   const uint32_t nbins = N / 2u;
-  const bool mapped = D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
+  const bool mapped = !LEAN && D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
   if (mapped)
     for (uint32_t i = lane; i < N; i += 64u) rowmap[i] = A.row_idx[D.row_idx_off + i];
   for (uint32_t i = lane; i < nbins; i += 64u) hist[i] = 0u;
@@ -211,6 +224,8 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) synhist[i] = 0u;
     cinfo[lane] = uint8_t(d_tables.syn3[lane] | (((d_tables.stop_mask >> lane) & 1ull) << 7));
     ainfo[lane] = d_tables.annot_info[lane];
+    for (uint32_t i = lane; i < sizeof(SingleLut) / 4u; i += 64u)
+      reinterpret_cast<uint32_t*>(slut)[i] = reinterpret_cast<const uint32_t*>(d_single_lut.v)[i];
   }
   __syncthreads();
 
@@ -298,16 +313,12 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       const bool pb = ((vd >> (8u * b)) & 0xFFu) != 0u && off < lim;
       const uint64_t m = __ballot(pb);
       if (pb) list[P + mbcnt64(m)] = uint16_t(off | ((vd >> (8u * b)) & 0xFFu) << 8);
-      if (A.var_bm != nullptr && lane == 0u)
+      if (!LEAN && A.var_bm != nullptr && lane == 0u)
         A.var_bm[(uint64_t)(D.tile_off + tile) * LB + b] = m;
       P += (uint32_t)__popcll(m);
     }
     P = __builtin_amdgcn_readfirstlane(P);
     acc_S += (lane == 0u) ? P : 0u;
-    if (cds) {
-#pragma unroll
-      for (uint32_t b = 0; b < (uint32_t)LB; ++b) hsite[LB * lane + b] = 0u;
-    }
     __syncthreads();
 
     // ---------------- tier 2: exact allele counts of the variable sites
@@ -316,7 +327,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     // per byte).  Otherwise (3+ alleles, ~1 % of variable sites) the column is walked again
     // with six counters, and any byte outside A C G T - N takes the exact generic path.
     const uint32_t slot = lane >> 2, ph = lane & 3u;
-    for (uint32_t p0 = 0; p0 < P && !(A.pad & 4u); p0 += 16u) {
+    for (uint32_t p0 = 0; p0 < P; p0 += 16u) {
       const uint32_t idx = p0 + slot;
       const bool act = idx < P;
       const uint32_t ent = list[act ? idx : 0u];
@@ -391,37 +402,17 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     // tile t starts t mod 3 sites before it.  Those sites (bytes of every row + their H) are
     // carried over in LDS from the previous tile of this wave's chunk; chunks of coding plans
     // hold a multiple of 3 tiles, so a chunk always starts on a codon boundary.
-    if (cds && !(A.pad & 1u)) {
-      __syncthreads();
-      auto h_at = [&](int rel) -> uint32_t { return hsite[rel]; };   // rel >= -2
+    if (cds) {
+      __syncthreads();   // tier 2's hsite entries are visible
       auto cell = [&](uint32_t r, int rel) -> uint32_t {
         const uint8_t* q = rel < 0 ? carry + 2u * r + (uint32_t)(2 + rel) : tile8 + r * G::WW + (uint32_t)rel;
         return *q;
       };
-      // Given the set M of distinct clean codons of a column (PolyFastA.py:301-315):
-      // synonymous-site numerator, stop flag, S / N labels of its variable positions.
-      auto finish_codon = [&](unsigned long long M, int rel, uint32_t h0, uint32_t h1, uint32_t h2) {
-        const uint32_t k = (uint32_t)__popcll(M);
-        if (k == 0u) { acc_missing += 1u; return; }
-        const uint32_t t3 = syn_thirds_of_mask(M, d_tables);
-        if (k == 1u) acc_syn1 += t3;
-        else atomicAdd(&synhist[k], t3);
-        acc_stops += (M & d_tables.stop_mask) != 0ull;
-        const unsigned long long Ms = M & ~d_tables.stop_mask;
-        if (k < 2u || __popcll(Ms) < 2) return;
-        const uint32_t labels = classify_sense_mask(Ms, d_tables, ainfo);
-        const uint32_t hs[3] = {h0 & 0xFFFFFFu, h1 & 0xFFFFFFu, h2 & 0xFFFFFFu};
-#pragma unroll
-        for (uint32_t p = 0; p < 3u; ++p) {
-          const bool is_s = (labels >> p) & 1u, is_n = (labels >> (3u + p)) & 1u;
-          if (is_s) { acc_segS += 1u; acc_HS += hs[p]; }
-          if (is_n) { acc_segN += 1u; acc_HN += hs[p]; }
-          if ((is_s || is_n) && A.syn_bm != nullptr) {   // optional per-site S / N bitmaps
-            const uint32_t site = site0 + (uint32_t)(rel + (int)p);   // rel + p may be -2..-1: previous tile
-            const uint64_t w = (uint64_t)(D.tile_off + site / G::WW) * LB + (site % G::WW) % LB;
-            atomicOr(&(is_s ? A.syn_bm : A.non_bm)[w], 1ull << ((site % G::WW) / LB));
-          }
-        }
+      // optional per-site S / N bitmaps
+      auto mark_site = [&](bool is_s, int rel_site) {
+        const uint32_t site = site0 + (uint32_t)rel_site;   // rel_site may be -2..-1: previous tile
+        const uint64_t w = (uint64_t)(D.tile_off + site / G::WW) * LB + (site % G::WW) % LB;
+        atomicOr(&(is_s ? A.syn_bm : A.non_bm)[w], 1ull << ((site % G::WW) / LB));
       };
 
       // Register window: every lane looks at the codon columns that END at one of its own
@@ -432,10 +423,10 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       uint32_t xw[2], dw[2];     // per candidate column: 3 consensus bytes, 3 XOR bytes (0 = monomorphic)
       int endo[2];               // tile-relative site where it ends, or -1
       if constexpr (LB == 4) {
-        uint32_t pa = __shfl_up(va, 1), pd = __shfl_up(vd, 1);
+        uint32_t pa = wave_shr1(va), pd = wave_shr1(vd);
         if (lane == 0u) { pa = carry_va; pd = carry_vd; }
-        carry_va = __shfl(va, 63);
-        carry_vd = __shfl(vd, 63);
+        carry_va = __builtin_amdgcn_readlane(va, 63);
+        carry_vd = __builtin_amdgcn_readlane(vd, 63);
         const unsigned long long Wa = (unsigned long long)pa | (unsigned long long)va << 32;
         const unsigned long long Wd = (unsigned long long)pd | (unsigned long long)vd << 32;
         const uint32_t o1 = (5u - (site0 + 4u * lane) % 3u) % 3u;   // first own site that ends a codon
@@ -461,19 +452,21 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
         endo[1] = -1;
       }
 
-      uint32_t PC = 0u, P1 = 0u;
+      constexpr uint32_t NIT = LB == 4 ? 2u : 1u;
+      uint64_t mjoint[2] = {0ull, 0ull};
+      bool single[2] = {false, false};
+      uint32_t pv[2] = {0u, 0u};
 #pragma unroll
-      for (uint32_t it = 0; it < (LB == 4 ? 2u : 1u); ++it) {
-        bool joint = false, single = false;
-        uint32_t pv = 0u;
+      for (uint32_t it = 0; it < NIT; ++it) {
+        bool joint = false;
         if (endo[it] >= 0) {
           const uint32_t w = xw[it], dv = dw[it];
           const bool v0 = (dv & 0xFFu) != 0u, v1 = (dv & 0xFF00u) != 0u, v2 = (dv & 0xFF0000u) != 0u;
           const uint32_t nvar = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
           joint = nvar >= 2u;                                // rare: the codons must be read row by row
-          single = nvar == 1u;                               // one variable position: second pass below
-          pv = v0 ? 0u : v1 ? 1u : 2u;
-          if (nvar == 0u && !(A.pad & 16u)) {
+          single[it] = nvar == 1u;                           // one variable position: resolved from its allele mask
+          pv[it] = v0 ? 0u : v1 ? 1u : 2u;
+          if (nvar == 0u) {
             // exactly-A/C/G/T test of the three bytes at once: the canonical byte of the 2-bit
             // code (x >> 1) & 3 is 0x41 + 2 code + 0x0F [code == 2]; a byte is clean iff it equals it
             const uint32_t t2 = w & 0x060606u;
@@ -489,105 +482,94 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
             }
           }
         }
-        const uint64_t mj = __ballot(joint);
-        if (joint) clist[PC + mbcnt64(mj)] = uint8_t(endo[it]);
-        PC += (uint32_t)__popcll(mj);
-        const uint64_t m1 = __ballot(single);
-        if (single) c1list[P1 + mbcnt64(m1)] = uint16_t((uint32_t)endo[it] | pv << 8);
-        P1 += (uint32_t)__popcll(m1);
+        mjoint[it] = __ballot(joint);
       }
-      P1 = __builtin_amdgcn_readfirstlane(P1);
-      if (P1 && !(A.pad & 8u)) {
-        __syncthreads();
-        // Columns with ONE variable position: the codon set is the consensus codon with every
-        // A/C/G/T allele of that position substituted (rows with another symbol there hold an
-        // unclean codon and drop out, PolyFastA.py:301).  Only that position can be labelled.
-        for (uint32_t idx = lane; idx < P1; idx += 64u) {
-          const uint32_t ent = c1list[idx];
-          const uint32_t p = ent >> 8;
-          const int rel = (int)(ent & 0xFFu) - 2;
-          const uint32_t hv = hsite[rel + (int)p];
-          const uint32_t am = hv >> 24;
-          const uint32_t y0 = cell(0u, rel + (p == 0u ? 1 : 0)), y1 = cell(0u, rel + (p == 2u ? 1 : 2));   // the two fixed bytes
-          const bool ok = base_clean(y0) && base_clean(y1);
-          const uint32_t sh = 4u - 2u * p;
-          const uint32_t base = p == 0u ? base_code(y0) * 4u + base_code(y1)
-                              : p == 1u ? base_code(y0) * 16u + base_code(y1)
-                                        : base_code(y0) * 16u + base_code(y1) * 4u;
-          uint32_t k = 0u, ks = 0u, t3 = 0u, stop = 0u, ids = 0u, fam = 0x60u;
-#pragma unroll
-          for (uint32_t e = 0; e < 4u; ++e) {
-            if (ok && ((am >> e) & 1u)) {
-              const uint32_t c = base | (e << sh);
-              const uint32_t ci = cinfo[c];
-              k += 1u;
-              t3 += ci & 7u;
-              if (ci >> 7) stop = 1u;
-              else {
-                const uint32_t ai = ainfo[c];
-                ids |= (ai & 0x1Fu) << (8u * ks);            // annotation ids of the sense codons, one per byte
-                fam &= ai;
-                ks += 1u;
-              }
-            }
+
+      // Columns with ONE variable position, on the lane that owns the column: the codon set is
+      // the consensus codon with every A/C/G/T allele of that position substituted (rows with
+      // another symbol there hold an unclean codon and drop out, PolyFastA.py:301).  Only that
+      // position can be labelled.  The two fixed bytes are the lane's consensus bytes; the
+      // allele mask and H of the variable site come from tier 2 (hsite).
+      auto single_col = [&](uint32_t w, uint32_t p, int end_rel) {
+        const int rel = end_rel - 2;
+        const uint32_t hv = hsite[rel + (int)p];
+        const uint32_t am = hv >> 24;
+        // exactly-A/C/G/T test of the two fixed bytes (as above; the byte of position p is meaningless)
+        const uint32_t t2 = w & 0x060606u;
+        const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
+        const uint32_t bad = ((0x414141u + t2 + (e2 << 4) - e2) ^ w) & ~(0xFFu << (8u * p));
+        const uint32_t k = bad ? 0u : (uint32_t)__popc(am);   // distinct clean codons
+        if (k == 0u) { acc_missing += 1u; return; }
+        const uint32_t tt = t2 >> 1;
+        const uint32_t c0 = tt & 3u, c1 = (tt >> 8) & 3u, c2 = (tt >> 16) & 3u;
+        const uint32_t b4 = p == 0u ? (c1 << 2 | c2) : p == 1u ? (c0 << 2 | c2) : (c0 << 2 | c1);
+        const uint32_t v = slut[(p * 16u + b4) * 16u + am];
+        const uint32_t t3 = v & 0x1Fu;
+        if (k == 1u) acc_syn1 += t3;
+        else atomicAdd(&synhist[k], t3);
+        acc_stops += (v >> 5) & 1u;
+        const bool is_s = (v & 0x40u) != 0u, is_n = (v & 0x80u) != 0u;
+        const uint32_t hs = hv & 0xFFFFFFu;
+        if (is_s) { acc_segS += 1u; acc_HS += hs; }
+        if (is_n) { acc_segN += 1u; acc_HN += hs; }
+        if (!LEAN && (is_s || is_n) && A.syn_bm != nullptr) mark_site(is_s, rel + (int)p);
+      };
+      {
+        const bool any1 = single[0] || single[1];
+        if (__any(any1)) {
+          if (any1) {
+            const uint32_t sel = single[0] ? 0u : 1u;
+            single_col(sel ? xw[1] : xw[0], sel ? pv[1] : pv[0], sel ? endo[1] : endo[0]);
           }
-          if (k == 0u) { acc_missing += 1u; continue; }
-          if (k == 1u) acc_syn1 += t3;
-          else atomicAdd(&synhist[k], t3);
-          acc_stops += stop;
-          if (ks < 2u) continue;
-          bool is_s, is_n;
-          if (ks == 2u) {                                    // two sense codons, one position: PolyFastA.py:349-358
-            is_s = (ids & 0xFFu) == (ids >> 8) || (p == 0u && fam != 0u);
-            is_n = !is_s;
-          } else {                                           // PolyFastA.py:415-432 with one variable position
-            // multiplicity of the most frequent annotation among the 3-4 sense codons
-            const uint32_t a = ids & 0xFFu, b = (ids >> 8) & 0xFFu, c = (ids >> 16) & 0xFFu, d = ks == 4u ? ids >> 24 : 0xFFu;
-            const uint32_t ma = 1u + (a == b) + (a == c) + (a == d), mb = 1u + (b == a) + (b == c) + (b == d);
-            const uint32_t mc = 1u + (c == a) + (c == b) + (c == d);
-            const uint32_t maxmult = umax(umax(ma, mb), mc);   // (d's own multiplicity is covered by its equals)
-            is_s = maxmult >= 2u && maxmult >= ks;
-            is_n = maxmult < 2u;
-          }
-          const uint32_t hs = hv & 0xFFFFFFu;
-          if (is_s) { acc_segS += 1u; acc_HS += hs; }
-          if (is_n) { acc_segN += 1u; acc_HN += hs; }
-          if ((is_s || is_n) && A.syn_bm != nullptr) {
-            const uint32_t site = site0 + (uint32_t)(rel + (int)p);
-            const uint64_t wi = (uint64_t)(D.tile_off + site / G::WW) * LB + (site % G::WW) % LB;
-            atomicOr(&(is_s ? A.syn_bm : A.non_bm)[wi], 1ull << ((site % G::WW) / LB));
-          }
+        }
+        const bool both = single[0] && single[1];            // a lane owning two such columns: rare
+        if (__any(both)) {
+          if (both) single_col(xw[1], pv[1], endo[1]);
         }
       }
       // the trailing 1-2 sites of an alignment whose length is not a multiple of 3 never form
       // a clean codon (PolyFastA.py:301-305)
       if (tile + 1u == n_tiles && (L % 3u) != 0u && lane == 0u) acc_missing += 1u;
-      PC = __builtin_amdgcn_readfirstlane(PC);
-      if (PC && !(A.pad & 2u)) {
-        __syncthreads();
-        // joint walk: GL lanes per codon column, as many as the wave allows (64 for a single
-        // column, 4 when 16 are pending), rows dealt round-robin; the lanes of a column OR their
-        // 64-bit codon sets into one LDS word (ds_or_b64) — cheaper than a 6-step 64-bit butterfly
-        unsigned long long* const jacc = reinterpret_cast<unsigned long long*>(c1list);   // c1list is dead by now
-        uint32_t lg = 2u;                                   // log2(GL)
-        while (lg < 6u && (PC << (lg + 1u)) <= 64u) ++lg;
-        const uint32_t GL = 1u << lg, slots = 64u >> lg;
-        const uint32_t jslot = lane >> lg, jph = lane & (GL - 1u);
-        for (uint32_t p0 = 0; p0 < PC; p0 += slots) {
-          const uint32_t idx = p0 + jslot;
-          const bool act = idx < PC;
-          const int rel = (int)clist[act ? idx : 0u] - 2;
-          unsigned long long M = 0ull;
-          if (jph == 0u) jacc[jslot] = 0ull;
-          for (uint32_t r = jph; r < N; r += GL) {
-            const int code = codon_of(cell(r, rel), cell(r, rel + 1), cell(r, rel + 2));
-            if (code >= 0) M |= 1ull << code;
+
+      // Columns with two or three variable positions (~0.6 %): one at a time, the whole wave
+      // reads the codon of one row per lane, the 64-bit codon-presence sets are OR-reduced with
+      // DPP moves (no LDS), and the classifier runs on the wave-uniform set
+      // (PolyFastA.py:301-315,319-434).
+      {
+#pragma unroll
+        for (uint32_t it = 0; it < NIT; ++it) {
+          for (uint64_t m = mjoint[it]; m != 0ull; m &= m - 1ull) {
+            const uint32_t owner = (uint32_t)__builtin_ctzll(m);
+            const int rel = __builtin_amdgcn_readlane(endo[it], owner) - 2;
+            unsigned long long Mv = 0ull;
+            for (uint32_t r = lane; r < N; r += 64u) {
+              const int code = codon_of(cell(r, rel), cell(r, rel + 1), cell(r, rel + 2));
+              if (code >= 0) Mv |= 1ull << code;
+            }
+            const unsigned long long M = wave_or_uniform(Mv);
+            const uint32_t k = (uint32_t)__popcll(M);
+            if (k == 0u) { acc_missing += lane == 0u ? 1u : 0u; continue; }
+            const uint32_t t3 = syn_thirds_of_mask(M, d_tables);
+            const bool stop = (M & d_tables.stop_mask) != 0ull;
+            const unsigned long long Ms = M & ~d_tables.stop_mask;
+            uint32_t labels = 0u;
+            if (k >= 2u && __popcll(Ms) >= 2) labels = classify_sense_mask(Ms, d_tables, ainfo);
+            if (lane == 0u) {
+              if (k == 1u) acc_syn1 += t3;
+              else atomicAdd(&synhist[k], t3);
+              acc_stops += stop ? 1u : 0u;
+#pragma unroll
+              for (uint32_t p = 0; p < 3u; ++p) {
+                const bool is_s = (labels >> p) & 1u, is_n = (labels >> (3u + p)) & 1u;
+                if (is_s || is_n) {
+                  const uint32_t hs = hsite[rel + (int)p] & 0xFFFFFFu;
+                  if (is_s) { acc_segS += 1u; acc_HS += hs; }
+                  else { acc_segN += 1u; acc_HN += hs; }
+                  if (!LEAN && A.syn_bm != nullptr) mark_site(is_s, rel + (int)p);
+                }
+              }
+            }
           }
-          __syncthreads();
-          if (M != 0ull) atomicOr(&jacc[jslot], M);
-          __syncthreads();
-          if (act && jph == 0u) finish_codon(jacc[jslot], rel, h_at(rel), h_at(rel + 1), h_at(rel + 2));
-          __syncthreads();
         }
       }
       // carry the last two columns (bytes of every row, H of the sites) into the next tile
@@ -1021,9 +1003,9 @@ static int launch_tall(const pfa_plan* p, const ScanArgs& a) {
   return PFA_OK;
 }
 
-template <int LB, int STAGE, bool CDS>
+template <int LB, int STAGE, bool CDS, bool LEAN>
 static int launch(const pfa_plan* p, const ScanArgs& a) {
-  auto kern = scan_kernel<LB, STAGE, CDS>;
+  auto kern = scan_kernel<LB, STAGE, CDS, LEAN>;
   static uint32_t lds_limit_set = 0;  // per instantiation; one process drives one device
   if (p->lds_bytes > lds_limit_set) {
     PFA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1353,20 +1335,23 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   a.rows_per_chunk = p->rows_per_chunk;
   a.max_slots = p->max_slots;
   a.hist_bins = p->hist_bins;
-  { const char* e = getenv("PFA_ABLATE"); a.pad = e ? (uint32_t)atoi(e) : 0u; }  // timing experiments only
+  a.pad = 0u;
 
   const int slot = (int)(p->n_runs % pfa::kEventRing);
   PFA_HIP(hipEventRecord(p->ev0[slot], st));
   int rc;
   // kernel STAGE: 2 = LDS-DMA non-temporal (default), 1 = register staging, 0 = LDS-DMA default cache policy
   const int stage = variant == 1 ? 1 : variant == 2 ? 0 : 2;
-#define PFA_LAUNCH(LB, CDS)                                            \
-  (stage == 0 ? pfa::launch<LB, 0, CDS>(p, a)                          \
-              : stage == 1 ? pfa::launch<LB, 1, CDS>(p, a) : pfa::launch<LB, 2, CDS>(p, a))
+#define PFA_LAUNCH(LB, CDS, LEAN)                                      \
+  (stage == 0 ? pfa::launch<LB, 0, CDS, LEAN>(p, a)                    \
+              : stage == 1 ? pfa::launch<LB, 1, CDS, LEAN>(p, a) : pfa::launch<LB, 2, CDS, LEAN>(p, a))
+  // lean instantiations (no row-index list, no bitmap) exist for the 256-site geometry
+  const bool lean = !p->use_rowmap && !p->d_var_bm && !p->d_syn_bm;
   if (p->tall)
     rc = stage == 0 ? pfa::launch_tall<0>(p, a) : stage == 1 ? pfa::launch_tall<1>(p, a) : pfa::launch_tall<2>(p, a);
-  else if (p->lb == 4) rc = p->any_cds ? PFA_LAUNCH(4, true) : PFA_LAUNCH(4, false);
-  else                 rc = p->any_cds ? PFA_LAUNCH(1, true) : PFA_LAUNCH(1, false);
+  else if (p->lb == 4 && lean) rc = p->any_cds ? PFA_LAUNCH(4, true, true) : PFA_LAUNCH(4, false, true);
+  else if (p->lb == 4)         rc = p->any_cds ? PFA_LAUNCH(4, true, false) : PFA_LAUNCH(4, false, false);
+  else                         rc = p->any_cds ? PFA_LAUNCH(1, true, false) : PFA_LAUNCH(1, false, false);
 #undef PFA_LAUNCH
   if (rc != PFA_OK) return rc;
   PFA_HIP(hipEventRecord(p->ev1[slot], st));
