@@ -15,7 +15,8 @@ tests/golden/example_theta_0.01/ATTRIBUTION).
 
 Families: G1 examples, G2 synthetic grid, G3 odd symbols and
 FASTA syntax, G4 exhaustive codon-set tables, G5 coding alignments, G6
-populations, G7 command-line transcripts.
+populations, G7 command-line transcripts, G8 the BASELINE.json configurations
+at their full sizes.
 """
 import contextlib
 import hashlib
@@ -433,7 +434,36 @@ def g7():
     dump("g7_cli.json", out)
 
 
+# ------------------------------------- G8 BASELINE.json configs at full size
+def g8():
+    """The CSV rows the reference prints for BASELINE.json configs 2, 3 and 4 at their
+    full sizes (config 1 is G1/G7's file1.fa; config 5 is a directory of config-2
+    alignments).  Config 3 goes through print_result per population, because
+    main() crashes on --pops (PolyFastA.py:126)."""
+    import time
+    out = []
+    cases = (
+        ("config2_N50_L10k", dict(seed=802, aln=0, N=50, L=10000, theta=0.01), [None], False, (False, True)),
+        ("config3_N200_L100k_pops_jc", dict(seed=803, aln=0, N=200, L=100000, theta=0.01, pops=2), ["pop1", "pop2"], False, (True,)),
+        ("config4_cds_N50_L9k", dict(seed=804, aln=0, N=50, L=9000, theta=0.01, coding=True), [None], True, (False, True)),
+    )
+    for label, g, keys, cds, jcs in cases:
+        d = gen_case(**g)
+        rows = {}
+        t0 = time.perf_counter()
+        for key in keys:
+            grp = d if key is None else {h: s for h, s in d.items() if key in h}
+            pop = "NA" if key is None else key
+            for jc in jcs:
+                row = capture(ref.print_result, grp, g["L"], cds, "", "a", "x.fa", pop, True, 0, jc).rstrip("\n")
+                assert_rows_close(orc.result_row(grp, g["L"], cds, "x.fa", pop, jc), row)
+                rows[f"{pop}|jc={int(jc)}"] = row
+        out.append({"label": label, "gen": g, "cds": cds, "pops": None if keys == [None] else keys, "rows": rows})
+        print(f"  {label}: {time.perf_counter() - t0:.1f} s (reference + oracle)")
+    dump("g8_baseline_configs.json", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         globals()[w]()

@@ -124,3 +124,23 @@ def test_pops_g6():
             grp = orc.split_pop(d, pop)
             got = orc.result_row(grp, case["gen"]["L"], cds == "cds=1", "x.fa", pop, jc == "jc=1")
             C.rows_close(got, want, rel=1e-10, rel_jc=1e-10)
+
+
+def test_baseline_configs_g8():
+    """BASELINE.json configs 2-4 at full size: the oracle prints the reference's rows."""
+    for case in C.load("g8_baseline_configs.json"):
+        g = case["gen"]
+        d = C.dict_from_gen(g)
+        m = C.matrix_from_gen(g)
+        for key, want in case["rows"].items():
+            pop, jc = key.split("|")[0], key.endswith("jc=1")
+            grp = d if case["pops"] is None else orc.split_pop(d, pop)
+            C.rows_close(orc.result_row(grp, g["L"], case["cds"], "x.fa", pop, jc), want, rel=REL, rel_jc=REL, jc=jc)
+            # the C restatement's integers reproduce the row's integer fields
+            rows = None if case["pops"] is None else [i for i, h in enumerate(d) if pop in h]
+            o = c_oracle.scan(m, rows=rows, cds=case["cds"])
+            f = want.split(",")
+            if case["cds"]:
+                assert (o["seg_S"], o["seg_N"], o["nstops"]) == (int(f[5]), int(f[6]), int(f[13]))
+            else:
+                assert o["S"] == int(f[4])
