@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8192, help="alignments per GPU per step")
+    ap.add_argument("--batch", type=int, default=32768, help="alignments per GPU per step (16.6 GB of bases at the default shape)")
     ap.add_argument("--rows", type=int, default=50)
     ap.add_argument("--sites", type=int, default=10000)
     ap.add_argument("--theta", type=float, default=0.01)

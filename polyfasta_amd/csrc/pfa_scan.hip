@@ -934,6 +934,14 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   }
 }
 
+// Result slab -> pinned host memory, written by the compute units.  (A hipMemcpyAsync here goes
+// through the SDMA engines, whose queues the runtime creates lazily: single copies were seen to
+// take ~8 ms, longer than a whole batch scan.)
+__global__ void __launch_bounds__(256) slab_to_host_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
 // ---------------------------------------------------------------- plans
 static constexpr uint32_t kMaxRowsWide = 600u;  // coding plans: LB = 4 (256-site tiles) up to here, LB = 1 above
 static constexpr uint32_t kTallMin = 64u;       // non-coding plans with more rows than this: scan_tall_kernel
@@ -965,6 +973,7 @@ struct pfa_plan {
   // by one pinned host slab (one D2H per fetch)
   uint8_t* d_slab = nullptr;
   uint8_t* h_slab = nullptr;
+  uint8_t* h_slab_dev = nullptr;   // the device's address of h_slab
   size_t slab_bytes = 0, off_sfs = 0, off_syn = 0;
   pfa_result* d_results = nullptr;
   uint32_t* d_sfs = nullptr;
@@ -1046,6 +1055,11 @@ int pfa_init(int device) {
   if (c.ready && c.device == device) return PFA_OK;
   if (c.ready) pfa_shutdown();
   PFA_HIP(hipSetDevice(device));
+  // host waits spin instead of sleeping on an interrupt: a blocked wait was seen to return
+  // up to 8 ms late on the GPU box, longer than a whole batch scan (hint only; ignored if the
+  // runtime already fixed its flags)
+  (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+  (void)hipGetLastError();
   hipDeviceProp_t prop;
   PFA_HIP(hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -1286,6 +1300,7 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
     p->slab_bytes = p->off_syn + (any_cds ? up((size_t)n_desc * PFA_SYN_BINS * sizeof(uint32_t)) : 0);
     PLAN_HIP(hipMalloc((void**)&p->d_slab, p->slab_bytes));
     PLAN_HIP(hipHostMalloc((void**)&p->h_slab, p->slab_bytes, hipHostMallocDefault));
+    PLAN_HIP(hipHostGetDevicePointer((void**)&p->h_slab_dev, p->h_slab, 0));
     p->d_results = reinterpret_cast<pfa_result*>(p->d_slab);
     p->d_sfs = reinterpret_cast<uint32_t*>(p->d_slab + p->off_sfs);
     p->d_syn = any_cds ? reinterpret_cast<uint32_t*>(p->d_slab + p->off_syn) : nullptr;
@@ -1381,8 +1396,12 @@ int pfa_plan_fetch(pfa_plan* p, pfa_result* results, uint32_t* sfs, uint32_t* sy
   const size_t nt = p->n_tiles_total;
   if (syn_num && !p->d_syn) { pfa::set_error("pfa_plan_fetch: plan has no coding unit"); return PFA_ERR_ARG; }
   if (results || sfs || syn_num) {
-    // one D2H into pinned memory, then plain memcpy into the caller's (pageable) arrays
-    PFA_HIP(hipMemcpyAsync(p->h_slab, p->d_slab, p->slab_bytes, hipMemcpyDeviceToHost, st));
+    // one device-side copy into pinned memory, then plain memcpy into the caller's (pageable) arrays
+    const size_t n16 = p->slab_bytes / 16u;   // slab sections are padded to 256 bytes
+    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255u) / 256u, 1024u);
+    hipLaunchKernelGGL(pfa::slab_to_host_kernel, dim3(blocks), dim3(256), 0, st,
+                       reinterpret_cast<const uint4*>(p->d_slab), reinterpret_cast<uint4*>(p->h_slab_dev), n16);
+    PFA_HIP(hipGetLastError());
     PFA_HIP(hipStreamSynchronize(st));
     if (results) memcpy(results, p->h_slab, (size_t)p->n_desc * sizeof(pfa_result));
     if (sfs && p->sfs_words) memcpy(sfs, p->h_slab + p->off_sfs, p->sfs_words * sizeof(uint32_t));
