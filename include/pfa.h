@@ -180,6 +180,9 @@ int64_t pfa_bitmap_positions(const uint64_t* words, uint32_t n_tiles, uint32_t w
  * A=0, C=1, T=2, G=3 (= (ascii >> 1) & 3).  Returns bits 0-2 = codon positions
  * called synonymous, bits 3-5 = non-synonymous (PolyFastA.py:319-434). */
 uint32_t pfa_classify_codon_mask(uint64_t mask);
+/* the same classification by the wave-uniform form the scan kernels use, on the device, for
+ * `n` sets at once (host pointers; used to check the device classifier exhaustively) */
+int pfa_classify_codon_masks_dev(const uint64_t* masks, uint32_t n, uint32_t* labels_out);
 /* synonymous single-nucleotide neighbours (0..4) of one codon = 3 x syncodfreq
  * (PolyFastA.py:536-557) */
 uint32_t pfa_codon_syn_thirds(uint32_t codon);

@@ -104,6 +104,7 @@ _PROTOTYPES = {
     "pfa_bitmap_positions": (ctypes.c_int64, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                               ctypes.c_uint32, _vp, ctypes.c_uint64]),
     "pfa_classify_codon_mask": (ctypes.c_uint32, [ctypes.c_uint64]),
+    "pfa_classify_codon_masks_dev": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
     "pfa_codon_syn_thirds": (ctypes.c_uint32, [ctypes.c_uint32]),
     "pfa_synth_fill_dev": (ctypes.c_int, [_vp, ctypes.POINTER(SynthParamsC), _vp, _vp]),
     "pfa_synth_fill_host": (ctypes.c_int, [_vp, ctypes.POINTER(SynthParamsC), _vp, _vp]),

@@ -154,7 +154,8 @@ def syncodfreq(cod):
 
 def get_syn_nonsyn_cod_sites(cod):
     """``cod`` = [list of unique codons, column start]; returns (S, N) absolute
-    positions.  Runs the same classifier code as the device path."""
+    positions (host evaluation of pfa_codon.h's classifier; the kernels run its
+    wave-uniform form, checked against the same vectors by classify_codon_sets_on_device)."""
     mask = 0
     for c in cod[0]:
         idx = _codon_index(c)
@@ -164,6 +165,25 @@ def get_syn_nonsyn_cod_sites(cod):
     syn = [p + cod[1] for p in range(3) if (bits >> p) & 1]
     non = [p + cod[1] for p in range(3) if (bits >> (3 + p)) & 1]
     return syn, non
+
+
+def classify_codon_sets_on_device(codon_sets):
+    """The classification of ``get_syn_nonsyn_cod_sites`` for many codon sets at once, by the
+    wave-uniform classifier the scan kernels run (bits 0-2 synonymous, bits 3-5
+    non-synonymous positions per set)."""
+    import numpy as np
+    masks = np.zeros(len(codon_sets), dtype=np.uint64)
+    for i, cods in enumerate(codon_sets):
+        m = 0
+        for c in cods:
+            idx = _codon_index(c)
+            if idx is not None:
+                m |= 1 << idx
+        masks[i] = m
+    out = np.zeros(len(masks), dtype=np.uint32)
+    _lib.init()
+    _lib.check(_lib.load().pfa_classify_codon_masks_dev(_lib.ptr(masks), len(masks), _lib.ptr(out)))
+    return out
 
 
 def getvarCDSsites(d, seqlen):

@@ -160,6 +160,7 @@ struct Tables {
   uint8_t syn3[64];       // syn_thirds
   uint64_t stop_mask;
   uint64_t t_mask[5];     // t_mask[v]: codons whose syn_thirds == v (v = 1..4)
+  uint64_t same_annot[64]; // sense codons carrying the same annotation label as codon c (0 for stops)
 };
 
 constexpr Tables make_tables() {
@@ -180,6 +181,9 @@ constexpr Tables make_tables() {
       if (!is_stop(d) && annot(d) == annot(c)) { id = t.annot_id[d]; break; }
     t.annot_id[c] = uint8_t(id >= 0 ? id : next++);
   }
+  for (int c = 0; c < 64; ++c)
+    for (int d = 0; d < 64; ++d)
+      if (!is_stop(c) && !is_stop(d) && t.annot_id[c] == t.annot_id[d]) t.same_annot[c] |= 1ull << d;
   for (int c = 0; c < 64; ++c) {
     if (is_stop(c)) { t.annot_info[c] = 255; continue; }
     const uint32_t a = annot(c);

@@ -53,7 +53,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-static constexpr ct::Tables kHostTables = ct::make_tables();
+static constexpr ct::Tables kHostTables = ct::make_tables();   // also the source of literal constants in device code
 
 }  // namespace pfa
 
@@ -183,6 +183,47 @@ __device__ inline int codon_of(uint32_t x0, uint32_t x1, uint32_t x2) {
   return ok ? int(base_code(x0) * 16u + base_code(x1) * 4u + base_code(x2)) : -1;
 }
 
+// Wave-uniform form of classify_sense_mask (pfa_codon.h; PolyFastA.py:331-434) for a set `ms`
+// held in scalar registers: lane c stands for codon c (`my_info` = annot_info[c], `my_same` =
+// same_annot[c]), so the multiplicity rule for three or more codons needs no loop — a codon's
+// label multiplicity is one popcount, and "some label occurs at least t times" is one ballot.
+__device__ inline uint32_t classify_uniform(unsigned long long ms, uint32_t lane, uint32_t my_info,
+                                            unsigned long long my_same) {
+  const int k = __popcll(ms);
+  if (k < 2) return 0u;
+  if (k == 2) {
+    const int c1 = __builtin_ctzll(ms);
+    const int c2 = __builtin_ctzll(ms & (ms - 1ull));
+    const uint32_t x = uint32_t(c1 ^ c2);
+    const bool d0 = (x & 0x30u) != 0u, d1 = (x & 0x0Cu) != 0u, d2 = (x & 0x03u) != 0u;
+    if (int(d0) + int(d1) + int(d2) == 1) {                       // PolyFastA.py:349-358
+      const uint32_t i1 = (uint32_t)__builtin_amdgcn_readlane((int)my_info, c1);
+      const uint32_t i2 = (uint32_t)__builtin_amdgcn_readlane((int)my_info, c2);
+      const bool syn = i1 == i2 || (d0 && (i1 & i2 & 0x60u) != 0u);
+      const uint32_t bit = d0 ? 1u : d1 ? 2u : 4u;
+      return syn ? bit : bit << 3;
+    }
+    return d_tables.pair[c1 * 64 + c2];                           // PolyFastA.py:360-414
+  }
+  // three or more distinct sense codons                          PolyFastA.py:415-432
+  uint32_t nb0 = 0, nb1 = 0, nb2 = 0;
+#pragma unroll
+  for (uint32_t e = 0; e < 4u; ++e) {
+    nb0 += (ms & (0xFFFFull << (16u * e))) != 0ull;
+    nb1 += (ms & (0x000F000F000F000Full << (4u * e))) != 0ull;
+    nb2 += (ms & (0x1111111111111111ull << e)) != 0ull;
+  }
+  const uint32_t var = (nb0 > 1u ? 1u : 0u) | (nb1 > 1u ? 2u : 0u) | (nb2 > 1u ? 4u : 0u);
+  const bool present = (ms >> lane) & 1ull;
+  const uint32_t mult = present ? (uint32_t)__popcll(ms & my_same) : 0u;
+  if (__ballot(mult >= 2u) == 0ull) return var << 3;              // all labels distinct: PolyFastA.py:430-432
+  const uint32_t last = (var & 4u) ? 2u : (var & 2u) ? 1u : 0u;
+  const uint32_t nb_last = last == 2u ? nb2 : last == 1u ? nb1 : nb0;
+  const uint32_t s = __ballot(mult >= nb_last) != 0ull ? (1u << last) : 0u;   // PolyFastA.py:426-427
+  const uint32_t n = var & ((1u << last) - 1u);                   // PolyFastA.py:428-429
+  return s | n << 3;
+}
+
 // ---------------------------------------------------------------- the kernel
 // LEAN: the plan has no row-index list and wants no per-site bitmap (the batch path of the CLI
 // and the bench): those branches, and the scalar registers they pin, are compiled out.
@@ -214,6 +255,9 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   uint8_t* const slut = lds + lo.slut;
   uint32_t* const synhist = reinterpret_cast<uint32_t*>(lds + lo.synhist);
 
+  // lane c stands for codon c in the wave-uniform classifier
+  const uint32_t my_info = HAS_CDS ? d_tables.annot_info[lane] : 0u;
+  const unsigned long long my_same = HAS_CDS ? d_tables.same_annot[lane] : 0ull;
   const uint32_t nbins = N / 2u;
   const bool mapped = !LEAN && D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
   if (mapped)
@@ -549,11 +593,11 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
             const unsigned long long M = wave_or_uniform(Mv);
             const uint32_t k = (uint32_t)__popcll(M);
             if (k == 0u) { acc_missing += lane == 0u ? 1u : 0u; continue; }
-            const uint32_t t3 = syn_thirds_of_mask(M, d_tables);
-            const bool stop = (M & d_tables.stop_mask) != 0ull;
-            const unsigned long long Ms = M & ~d_tables.stop_mask;
-            uint32_t labels = 0u;
-            if (k >= 2u && __popcll(Ms) >= 2) labels = classify_sense_mask(Ms, d_tables, ainfo);
+            constexpr unsigned long long kStop = kHostTables.stop_mask;
+            const uint32_t t3 = (uint32_t)__popcll(M & kHostTables.t_mask[1]) + 2u * (uint32_t)__popcll(M & kHostTables.t_mask[2]) +
+                                3u * (uint32_t)__popcll(M & kHostTables.t_mask[3]) + 4u * (uint32_t)__popcll(M & kHostTables.t_mask[4]);
+            const bool stop = (M & kStop) != 0ull;
+            const uint32_t labels = classify_uniform(M & ~kStop, lane, my_info, my_same);
             if (lane == 0u) {
               if (k == 1u) acc_syn1 += t3;
               else atomicAdd(&synhist[k], t3);
@@ -931,6 +975,21 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   for (uint32_t i = lane; i < HB; i += 64u) {
     const uint32_t v = hist[i];
     if (v) atomicAdd(&A.sfs[D.sfs_off + i], v);
+  }
+}
+
+// The device classifier on a list of codon sets (test entry point: pfa_classify_codon_masks_dev)
+__global__ void __launch_bounds__(64) classify_masks_kernel(const unsigned long long* __restrict__ masks, uint32_t n,
+                                                            uint32_t* __restrict__ labels) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t my_info = d_tables.annot_info[lane];
+  const unsigned long long my_same = d_tables.same_annot[lane];
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const unsigned long long m = masks[i];
+    const unsigned long long mu = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m) |
+                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32;
+    const uint32_t lab = classify_uniform(mu & ~kHostTables.stop_mask, lane, my_info, my_same);
+    if (lane == 0u) labels[i] = lab;
   }
 }
 
@@ -1486,6 +1545,28 @@ int64_t pfa_bitmap_positions(const uint64_t* words, uint32_t n_tiles, uint32_t w
 
 uint32_t pfa_classify_codon_mask(uint64_t mask) {
   return pfa::classify_sense_mask(mask & ~pfa::kHostTables.stop_mask, pfa::kHostTables, pfa::kHostTables.annot_info);
+}
+
+int pfa_classify_codon_masks_dev(const uint64_t* masks, uint32_t n, uint32_t* labels_out) {
+  PFA_NEED_INIT();
+  if (n == 0) return PFA_OK;
+  if (!masks || !labels_out) { pfa::set_error("pfa_classify_codon_masks_dev: NULL argument"); return PFA_ERR_ARG; }
+  hipStream_t st = pfa::ctx().stream;
+  unsigned long long* d_m = nullptr;
+  uint32_t* d_l = nullptr;
+  PFA_HIP(hipMalloc((void**)&d_m, (size_t)n * 8u));
+  if (hipMalloc((void**)&d_l, (size_t)n * 4u) != hipSuccess) { (void)hipFree(d_m); pfa::set_error("hipMalloc failed"); return PFA_ERR_HIP; }
+  hipError_t e = hipMemcpyAsync(d_m, masks, (size_t)n * 8u, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(pfa::classify_masks_kernel, dim3(std::min<uint32_t>(n, 4096u)), dim3(64), 0, st, d_m, n, d_l);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(labels_out, d_l, (size_t)n * 4u, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_m);
+  (void)hipFree(d_l);
+  if (e != hipSuccess) { pfa::set_error("pfa_classify_codon_masks_dev: %s", hipGetErrorString(e)); return PFA_ERR_HIP; }
+  return PFA_OK;
 }
 
 uint32_t pfa_codon_syn_thirds(uint32_t codon) { return codon < 64u ? pfa::kHostTables.syn3[codon] : 0u; }

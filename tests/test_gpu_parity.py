@@ -233,3 +233,27 @@ def test_full_size_batch_properties(gpu):
     assert int(o2.results["H"].sum()) == int(res[0]["H"])
     assert (o2.sfs_flat.reshape(2, N // 2).sum(axis=0) == sfs[0]).all()
     dev.free()
+
+
+def test_device_classifier_all_codon_sets(gpu):
+    """G4 through the classifier the kernels run (wave-uniform form): all 1 830 pairs,
+    all 35 990 triples and the random larger sets frozen from the reference, plus sets
+    with stop codons mixed in (the kernels strip them, PolyFastA.py:331)."""
+    import itertools
+    from polyfasta_amd import api
+    g4 = C.load("g4_codon_sets.json")
+    sense = g4["sense"]
+    sets = [list(p) for p in itertools.combinations(sense, 2)]
+    want = list(g4["pairs"])
+    sets += [list(t) for t in itertools.combinations(sense, 3)]
+    want += list(bytes.fromhex(g4["triples"]))
+    for cs, w in g4["sets"]:
+        sets.append([cs[i:i + 3] for i in range(0, len(cs), 3)])
+        want.append(w)
+    n_plain = len(sets)
+    for i in range(0, n_plain, 7):          # the same sets with stops mixed in classify the same
+        sets.append(sets[i] + ["TAA", "TGA"])
+        want.append(want[i])
+    got = api.classify_codon_sets_on_device(sets)
+    bad = np.flatnonzero(got != np.array(want, dtype=np.uint32))
+    assert len(bad) == 0, (len(bad), sets[bad[0]], int(got[bad[0]]), want[bad[0]])
