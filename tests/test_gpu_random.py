@@ -63,6 +63,33 @@ def test_random_batches(gpu, seed):
         _compare(out, i, c_oracle.scan(m, rows=rows, cds=cds, want_sites=True), cds)
 
 
+@pytest.mark.parametrize("seed,cds", [(0, False), (1, True), (2, True), (3, True)])
+def test_random_batches_lean_kernels(gpu, seed, cds):
+    """Plans without row subsets and without bitmaps run the lean instantiations (the batch
+    path of the CLI and the bench): same integers as the oracle."""
+    rng = np.random.default_rng(777 + seed)
+    b = scan.Batch(stride_align=[128, 16, 128, 64][seed])
+    units = []
+    for _ in range(80):
+        n = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 50, 64]))      # coding or not, at most 64 rows: scan_kernel<4, ., ., true>
+        L = int(rng.choice([1, 2, 3, 15, 16, 17, 255, 256, 257, 258, 511, 512, 513, 767, 768, 769, 770, 1000, 1537, 3001, 9000]))
+        alpha = ALPHABETS[int(rng.integers(0, 4))]
+        m = _random_matrix(rng, n, L, alpha, float(rng.choice([0.0, 0.001, 0.01, 0.02, 0.05, 0.3])))
+        b.add_unit(b.add_matrix(m), cds=cds)
+        units.append(m)
+    out = scan.scan_batch(b)
+    from polyfasta_amd import stats
+    for i, m in enumerate(units):
+        o = c_oracle.scan(m, cds=cds)
+        r = out.results[i]
+        assert (int(r["seg_sites"]), int(r["H"]), int(r["sfs_bad"])) == (o["S"], o["H"], o["sfs_bad"]), (i, m.shape)
+        assert out.sfs(i).tolist() == o["sfs"].tolist()
+        if cds:
+            assert (int(r["seg_S"]), int(r["seg_N"]), int(r["H_S"]), int(r["H_N"]), int(r["nstops"]), int(r["missing_cols"])) == \
+                   (o["seg_S"], o["seg_N"], o["H_S"], o["H_N"], o["nstops"], o["missing_cols"]), (i, m.shape)
+            assert abs(stats.syn_sites_from_bins(out.syn_num[i]) - o["count_syn"]) <= 1e-9 * max(1.0, o["count_syn"])
+
+
 def test_random_many_rows(gpu):
     """coding plans whose largest unit has more than 600 rows run the 64-site-tile kernel for every unit"""
     rng = np.random.default_rng(99)
