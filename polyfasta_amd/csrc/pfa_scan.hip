@@ -11,7 +11,7 @@
 //
 // Kernel shape.  One 64-lane wavefront per workgroup; no
 // inter-wave synchronisation anywhere.  A wavefront owns a chunk of
-// consecutive column tiles of one unit.  Per tile:
+// consecutive column tiles of one unit.  Per tile (scan_kernel):
 //   stage   N rows x 64*LB sites -> LDS with LDS-DMA (global_load_lds_dwordx4,
 //           one KiB per instruction, no VGPR round trip); each instruction
 //           covers 1024/(64*LB) rows so every lane moves 16 contiguous bytes
@@ -20,12 +20,16 @@
 //           monomorphic iff AND == OR (2 VALU ops per row per lane)
 //   compact ballot + mbcnt turn the per-lane flags into a dense list of the
 //           tile's variable sites (typically ~4 % of the sites)
-//   tier 2  4 lanes per variable site walk the column out of LDS, count
-//           A C G T - N with compare/add-carry, butterfly-reduce with two
-//           lane shuffles; any other byte takes an exact generic path
-//           (sum_i #{j : x_j = x_i}); H, SFS bin (LDS histogram), bitmaps
-//   coding  4 lanes per variable codon column OR a 64-bit codon-presence mask
-//           down the rows; the classifier runs on the mask (pfa_codon.h)
+//   tier 2  4 lanes per variable site walk the column out of LDS: two-allele
+//           fast path (x = row 0's byte, y = x ^ XOR byte), else six counters
+//           A C G T - N, else an exact generic path (sum_i #{j : x_j = x_i});
+//           H, SFS bin (LDS histogram), optional bitmaps
+//   coding  register window over the tier-1 words: monomorphic codon columns
+//           from a LUT, columns with one variable position from a compile-time
+//           table on the owning lane, columns with two or three (rare) read
+//           row by row, OR-reduced with DPP and classified wave-uniformly
+// Units of more than 64 rows without a coding flag run scan_tall_kernel, which
+// streams the rows of a tile in chunks (LDS per wave independent of N).
 // Per-chunk partial sums leave through integer atomics (order-independent).
 #include <algorithm>
 #include <cstdarg>
@@ -284,48 +288,53 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   const uint32_t n_inst = (N + G::RPI - 1u) / G::RPI;
   const uint32_t NN = N * N;
 
-  for (uint32_t tile = t0; tile < t1; ++tile) {
+  // ---------------- stage a column tile into LDS (asynchronous for the LDS-DMA variants)
+  auto stage = [&](uint32_t tile) {
     const uint32_t site0 = tile * TW;
-    const uint32_t lim = umin(TW, L - site0);  // valid sites of this tile
-
-    // ---------------- stage the column tile into LDS
-    {
-      const uint32_t c = lane % G::LPR, rr = lane / G::LPR;
-      const uint32_t col = umin(site0 + 16u * c, D.row_stride - 16u);
-      if constexpr (STAGE != 1) {
-        // STAGE 0: default cache policy; STAGE 2: non-temporal (aux = 2), the bases are read once
-        if (!mapped) {
-          // a running per-lane pointer; only the last instruction can be partial (EXEC-masked lanes
-          // move nothing and leave their LDS slot untouched)
-          const uint8_t* src = mat + (uint64_t)rr * D.row_stride + col;
-          const uint64_t step = (uint64_t)G::RPI * D.row_stride;
-          const uint32_t n_full = N / G::RPI;
-          uint32_t g = 0;
-          for (; g < n_full; ++g, src += step)
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
-          if (rr < N % G::RPI)
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
-        } else {
-          for (uint32_t g = 0; g < n_inst; ++g) {
-            const uint32_t r = g * G::RPI + rr;
-            if (r < N) {
-              const uint8_t* src = mat + (uint64_t)rowmap[r] * D.row_stride + col;
-              __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
-            }
-          }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t c = lane % G::LPR, rr = lane / G::LPR;
+    const uint32_t col = umin(site0 + 16u * c, D.row_stride - 16u);
+    if constexpr (STAGE != 1) {
+      // STAGE 0: default cache policy; STAGE 2: non-temporal (aux = 2), the bases are read once
+      if (!mapped) {
+        // a running per-lane pointer; only the last instruction can be partial (EXEC-masked lanes
+        // move nothing and leave their LDS slot untouched)
+        const uint8_t* src = mat + (uint64_t)rr * D.row_stride + col;
+        const uint64_t step = (uint64_t)G::RPI * D.row_stride;
+        const uint32_t n_full = N / G::RPI;
+        uint32_t g = 0;
+        for (; g < n_full; ++g, src += step)
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
+        if (rr < N % G::RPI)
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
       } else {
-#pragma unroll 4
         for (uint32_t g = 0; g < n_inst; ++g) {
           const uint32_t r = g * G::RPI + rr;
           if (r < N) {
-            const uint4 v = *reinterpret_cast<const uint4*>(mat + (uint64_t)(mapped ? rowmap[r] : r) * D.row_stride + col);
-            *reinterpret_cast<uint4*>(tile8 + g * 1024u + lane * 16u) = v;
+            const uint8_t* src = mat + (uint64_t)rowmap[r] * D.row_stride + col;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
           }
         }
       }
+    } else {
+#pragma unroll 4
+      for (uint32_t g = 0; g < n_inst; ++g) {
+        const uint32_t r = g * G::RPI + rr;
+        if (r < N) {
+          const uint4 v = *reinterpret_cast<const uint4*>(mat + (uint64_t)(mapped ? rowmap[r] : r) * D.row_stride + col);
+          *reinterpret_cast<uint4*>(tile8 + g * 1024u + lane * 16u) = v;
+        }
+      }
     }
+  };
+  // The tile of iteration t+1 is requested as soon as iteration t has read the last byte it needs
+  // from the tile buffer; what is left of iteration t by then (register / table work of the coding
+  // pass) runs under the loads.
+  stage(t0);
+
+  for (uint32_t tile = t0; tile < t1; ++tile) {
+    const uint32_t site0 = tile * TW;
+    const uint32_t lim = umin(TW, L - site0);  // valid sites of this tile
+    if constexpr (STAGE != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // ---------------- tier 1: running AND / OR down the rows
@@ -498,35 +507,92 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
 
       constexpr uint32_t NIT = LB == 4 ? 2u : 1u;
       uint64_t mjoint[2] = {0ull, 0ull};
-      bool single[2] = {false, false};
+      bool single[2] = {false, false}, mono[2] = {false, false};
       uint32_t pv[2] = {0u, 0u};
 #pragma unroll
       for (uint32_t it = 0; it < NIT; ++it) {
         bool joint = false;
         if (endo[it] >= 0) {
-          const uint32_t w = xw[it], dv = dw[it];
+          const uint32_t dv = dw[it];
           const bool v0 = (dv & 0xFFu) != 0u, v1 = (dv & 0xFF00u) != 0u, v2 = (dv & 0xFF0000u) != 0u;
           const uint32_t nvar = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
           joint = nvar >= 2u;                                // rare: the codons must be read row by row
           single[it] = nvar == 1u;                           // one variable position: resolved from its allele mask
+          mono[it] = nvar == 0u;
           pv[it] = v0 ? 0u : v1 ? 1u : 2u;
-          if (nvar == 0u) {
-            // exactly-A/C/G/T test of the three bytes at once: the canonical byte of the 2-bit
-            // code (x >> 1) & 3 is 0x41 + 2 code + 0x0F [code == 2]; a byte is clean iff it equals it
-            const uint32_t t2 = w & 0x060606u;
-            const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
-            const uint32_t bad = (0x414141u + t2 + (e2 << 4) - e2) ^ w;
-            if (bad == 0u) {
-              const uint32_t tt = t2 >> 1;
-              const uint32_t ci = cinfo[((tt & 3u) << 4) | ((tt >> 6) & 0xCu) | ((tt >> 16) & 3u)];
-              acc_syn1 += ci & 7u;
-              acc_stops += ci >> 7;
-            } else {
-              acc_missing += 1u;
+        }
+        mjoint[it] = __ballot(joint);
+      }
+
+      // Columns with two or three variable positions (~0.6 %): one at a time, the whole wave
+      // reads the codon of one row per lane, the 64-bit codon-presence sets are OR-reduced with
+      // DPP moves (no LDS), and the classifier runs on the wave-uniform set
+      // (PolyFastA.py:301-315,319-434).
+      {
+#pragma unroll
+        for (uint32_t it = 0; it < NIT; ++it) {
+          for (uint64_t m = mjoint[it]; m != 0ull; m &= m - 1ull) {
+            const uint32_t owner = (uint32_t)__builtin_ctzll(m);
+            const int rel = __builtin_amdgcn_readlane(endo[it], owner) - 2;
+            unsigned long long Mv = 0ull;
+            for (uint32_t r = lane; r < N; r += 64u) {
+              const int code = codon_of(cell(r, rel), cell(r, rel + 1), cell(r, rel + 2));
+              if (code >= 0) Mv |= 1ull << code;
+            }
+            const unsigned long long M = wave_or_uniform(Mv);
+            const uint32_t k = (uint32_t)__popcll(M);
+            if (k == 0u) { acc_missing += lane == 0u ? 1u : 0u; continue; }
+            constexpr unsigned long long kStop = kHostTables.stop_mask;
+            const uint32_t t3 = (uint32_t)__popcll(M & kHostTables.t_mask[1]) + 2u * (uint32_t)__popcll(M & kHostTables.t_mask[2]) +
+                                3u * (uint32_t)__popcll(M & kHostTables.t_mask[3]) + 4u * (uint32_t)__popcll(M & kHostTables.t_mask[4]);
+            const bool stop = (M & kStop) != 0ull;
+            const uint32_t labels = classify_uniform(M & ~kStop, lane, my_info, my_same);
+            if (lane == 0u) {
+              if (k == 1u) acc_syn1 += t3;
+              else atomicAdd(&synhist[k], t3);
+              acc_stops += stop ? 1u : 0u;
+#pragma unroll
+              for (uint32_t p = 0; p < 3u; ++p) {
+                const bool is_s = (labels >> p) & 1u, is_n = (labels >> (3u + p)) & 1u;
+                if (is_s || is_n) {
+                  const uint32_t hs = hsite[rel + (int)p] & 0xFFFFFFu;
+                  if (is_s) { acc_segS += 1u; acc_HS += hs; }
+                  else { acc_segN += 1u; acc_HN += hs; }
+                  if (!LEAN && A.syn_bm != nullptr) mark_site(is_s, rel + (int)p);
+                }
+              }
             }
           }
         }
-        mjoint[it] = __ballot(joint);
+      }
+      // carry the last two columns (bytes of every row) into the next tile
+      for (uint32_t i = lane; i < N; i += 64u) {
+        carry[2u * i] = tile8[i * G::WW + G::WW - 2u];
+        carry[2u * i + 1u] = tile8[i * G::WW + G::WW - 1u];
+      }
+      // ---- nothing below reads the tile buffer: request the next tile now
+      __syncthreads();
+      if (tile + 1u < t1) stage(tile + 1u);
+
+      // monomorphic columns: exactly-A/C/G/T test of the three consensus bytes at once (the
+      // canonical byte of the 2-bit code (x >> 1) & 3 is 0x41 + 2 code + 0x0F [code == 2]; a byte
+      // is clean iff it equals it), then one LUT read: synonymous weight | stop << 7
+#pragma unroll
+      for (uint32_t it = 0; it < NIT; ++it) {
+        if (mono[it]) {
+          const uint32_t w = xw[it];
+          const uint32_t t2 = w & 0x060606u;
+          const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
+          const uint32_t bad = (0x414141u + t2 + (e2 << 4) - e2) ^ w;
+          if (bad == 0u) {
+            const uint32_t tt = t2 >> 1;
+            const uint32_t ci = cinfo[((tt & 3u) << 4) | ((tt >> 6) & 0xCu) | ((tt >> 16) & 3u)];
+            acc_syn1 += ci & 7u;
+            acc_stops += ci >> 7;
+          } else {
+            acc_missing += 1u;
+          }
+        }
       }
 
       // Columns with ONE variable position, on the lane that owns the column: the codon set is
@@ -575,56 +641,12 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       // a clean codon (PolyFastA.py:301-305)
       if (tile + 1u == n_tiles && (L % 3u) != 0u && lane == 0u) acc_missing += 1u;
 
-      // Columns with two or three variable positions (~0.6 %): one at a time, the whole wave
-      // reads the codon of one row per lane, the 64-bit codon-presence sets are OR-reduced with
-      // DPP moves (no LDS), and the classifier runs on the wave-uniform set
-      // (PolyFastA.py:301-315,319-434).
-      {
-#pragma unroll
-        for (uint32_t it = 0; it < NIT; ++it) {
-          for (uint64_t m = mjoint[it]; m != 0ull; m &= m - 1ull) {
-            const uint32_t owner = (uint32_t)__builtin_ctzll(m);
-            const int rel = __builtin_amdgcn_readlane(endo[it], owner) - 2;
-            unsigned long long Mv = 0ull;
-            for (uint32_t r = lane; r < N; r += 64u) {
-              const int code = codon_of(cell(r, rel), cell(r, rel + 1), cell(r, rel + 2));
-              if (code >= 0) Mv |= 1ull << code;
-            }
-            const unsigned long long M = wave_or_uniform(Mv);
-            const uint32_t k = (uint32_t)__popcll(M);
-            if (k == 0u) { acc_missing += lane == 0u ? 1u : 0u; continue; }
-            constexpr unsigned long long kStop = kHostTables.stop_mask;
-            const uint32_t t3 = (uint32_t)__popcll(M & kHostTables.t_mask[1]) + 2u * (uint32_t)__popcll(M & kHostTables.t_mask[2]) +
-                                3u * (uint32_t)__popcll(M & kHostTables.t_mask[3]) + 4u * (uint32_t)__popcll(M & kHostTables.t_mask[4]);
-            const bool stop = (M & kStop) != 0ull;
-            const uint32_t labels = classify_uniform(M & ~kStop, lane, my_info, my_same);
-            if (lane == 0u) {
-              if (k == 1u) acc_syn1 += t3;
-              else atomicAdd(&synhist[k], t3);
-              acc_stops += stop ? 1u : 0u;
-#pragma unroll
-              for (uint32_t p = 0; p < 3u; ++p) {
-                const bool is_s = (labels >> p) & 1u, is_n = (labels >> (3u + p)) & 1u;
-                if (is_s || is_n) {
-                  const uint32_t hs = hsite[rel + (int)p] & 0xFFFFFFu;
-                  if (is_s) { acc_segS += 1u; acc_HS += hs; }
-                  else { acc_segN += 1u; acc_HN += hs; }
-                  if (!LEAN && A.syn_bm != nullptr) mark_site(is_s, rel + (int)p);
-                }
-              }
-            }
-          }
-        }
-      }
-      // carry the last two columns (bytes of every row, H of the sites) into the next tile
-      __syncthreads();
-      for (uint32_t i = lane; i < N; i += 64u) {
-        carry[2u * i] = tile8[i * G::WW + G::WW - 2u];
-        carry[2u * i + 1u] = tile8[i * G::WW + G::WW - 1u];
-      }
+      // H of the last two sites, for the codons that straddle into the next tile
       if (lane < 2u) hsite[(int)lane - 2] = hsite[G::WW - 2u + lane];
+    } else {
+      __syncthreads();   // every read of the tile buffer is done: request the next tile
+      if (tile + 1u < t1) stage(tile + 1u);
     }
-    __syncthreads();  // tile buffer is reused by the next iteration
   }
 
   // ---------------- flush the chunk's partial sums
