@@ -250,6 +250,24 @@ int pfa_fasta_load_files(const char* const* paths, uint32_t n_files, uint32_t st
                          char* names_out, uint64_t names_cap, uint64_t* bytes_used,
                          uint64_t* names_used);
 
+/* ---- CSV rows (host; PolyFastA.py:182-198, 502-520) --------------------------
+ * Formats the non-coding row of `n` scan units exactly as the reference prints it:
+ * "<prefix>S,pi,theta,D\n" with Python's repr() of the doubles, or "<prefix>0,0,0,NA\n"
+ * for a unit without variable sites.  prefix i = prefix_blob[prefix_off[i] ..
+ * prefix_off[i+1]) is the caller's "file,seqlen,pop,N," text.  a1 / e1 / e2 are the
+ * sample-size constants of PolyFastA.py:494-497, 522-533 for row i's N (computed by the
+ * caller, so their rounding is the host language's).  Returns the bytes written, or
+ * PFA_ERR_ARG; when a row would make the reference raise (math domain error in Dvar)
+ * *bad_row is set to its index and nothing is to be used from `out`. */
+int64_t pfa_format_plain_rows(const char* prefix_blob, const uint64_t* prefix_off, uint32_t n,
+                              const uint32_t* seg_sites, const uint64_t* h_sum, /* pfa_result.seg_sites, .H */
+                              const uint32_t* n_rows, const double* seqlen,
+                              const double* a1, const double* e1, const double* e2, int jc,
+                              char* out, uint64_t cap, int64_t* bad_row);
+/* repr(float) of CPython 3 into out32 (at least 32 bytes, not NUL-terminated);
+ * returns the length */
+int pfa_format_double(double x, char* out32);
+
 /* pinned (page-locked) host memory for the ingest buffer: pre-faulted, and H2D
  * from it runs at the PCIe rate */
 int pfa_host_alloc(size_t bytes, void** out);

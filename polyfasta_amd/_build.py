@@ -6,7 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libpfa_hip.so")
-SOURCES = ["pfa_scan.hip", "pfa_synth.hip", "pfa_fasta.cpp"]
+SOURCES = ["pfa_scan.hip", "pfa_synth.hip", "pfa_fasta.cpp", "pfa_format.cpp"]
 HEADERS = ["pfa_codon.h", "pfa_common.h", os.path.join("..", "..", "include", "pfa.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-fconstexpr-steps=500000000", "-Wall", "-Wno-unused-function"]

@@ -103,6 +103,9 @@ _PROTOTYPES = {
                                       _vp, _vp, _vp, _vp, _vp, _vp]),
     "pfa_bitmap_positions": (ctypes.c_int64, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                               ctypes.c_uint32, _vp, ctypes.c_uint64]),
+    "pfa_format_plain_rows": (ctypes.c_int64, [_vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
+                                               _vp, ctypes.c_uint64, _vp]),
+    "pfa_format_double": (ctypes.c_int, [ctypes.c_double, _vp]),
     "pfa_classify_codon_mask": (ctypes.c_uint32, [ctypes.c_uint64]),
     "pfa_classify_codon_masks_dev": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),
     "pfa_codon_syn_thirds": (ctypes.c_uint32, [ctypes.c_uint32]),

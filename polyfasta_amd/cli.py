@@ -121,6 +121,17 @@ class Sink:
         else:
             print(text)
 
+    def bulk_ok(self):
+        """a block of rows can go out in one piece when no per-row progress line is due"""
+        return not self.out or self.silent
+
+    def rows(self, block):
+        """`block`: rows separated and terminated by newlines"""
+        if self.out:
+            self._write(block[:-1])
+        else:
+            sys.stdout.write(block)
+
     def row(self, text, name, pop):
         if self.out:
             if not self.silent:
@@ -320,18 +331,75 @@ def process_files(indexed_paths, args):
     return done
 
 
+def format_plain_rows_native(units, jc):
+    """The non-coding rows of many units in one call into the library
+    (csrc/pfa_format.cpp: polymorphism() and repr(float) reproduced bit for bit).
+    `units`: sequences (name, pop, n_rows, seqlen, record tuple).  Returns the rows as one
+    text block ending in a newline, or None when some row needs the Python path (the
+    reference would raise there)."""
+    import ctypes
+    from . import _lib
+    n = len(units)
+    prefixes = [f"{u[0]},{u[3]},{u[1]},{u[2]}," for u in units]
+    blob = "".join(prefixes).encode()
+    lens = np.fromiter(map(len, prefixes), dtype=np.uint64, count=n)
+    if int(lens.sum()) != len(blob):                       # non-ASCII names: lengths in bytes
+        lens = np.fromiter((len(x.encode()) for x in prefixes), dtype=np.uint64, count=n)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    seg = np.fromiter((u[4][_SEG] for u in units), dtype=np.uint32, count=n)
+    hsum = np.fromiter((u[4][_H] for u in units), dtype=np.uint64, count=n)
+    nrows = np.fromiter((u[2] for u in units), dtype=np.uint32, count=n)
+    seqlen = np.fromiter((u[3] for u in units), dtype=np.float64, count=n)
+    uniq, inv = np.unique(nrows, return_inverse=True)
+    tab = np.array([((stats.harmonic_terms(int(k))[0],) + stats.tajima_e(int(k))) if k >= 2 else (0.0, 0.0, 0.0)
+                    for k in uniq], dtype=np.float64).reshape(-1, 3)
+    a1, e1, e2 = (np.ascontiguousarray(tab[inv, c]) for c in range(3))
+    out = np.empty(len(blob) + 128 * n + 16, dtype=np.uint8)
+    bad = ctypes.c_int64(-1)
+    got = _lib.load().pfa_format_plain_rows(blob, _lib.ptr(off), n, _lib.ptr(seg), _lib.ptr(hsum), _lib.ptr(nrows),
+                                            _lib.ptr(seqlen), _lib.ptr(a1), _lib.ptr(e1), _lib.ptr(e2), int(bool(jc)),
+                                            _lib.ptr(out), len(out), ctypes.byref(bad))
+    if got < 0:
+        if bad.value >= 0:
+            return None
+        _lib.check(got)
+    return out[:got].tobytes().decode()
+
+
+NATIVE_ROWS_MIN = 64      # below this the per-row Python path is as fast
+
+
 def emit(events, sink, cds, jc):
     """Finish the floats and write the rows / comment lines in order."""
-    for ev in events:
+    i, n = 0, len(events)
+    while i < n:
+        ev = events[i]
         if ev[1] == "comment":
             sink.comment(ev[2])
+            i += 1
         elif ev[1] == "stdout":
             print(ev[2])
+            i += 1
         else:
-            _, _, name, pop, n_rows, seqlen, res, syn = ev
-            text = (format_cds_row(name, pop, n_rows, seqlen, res, syn, jc) if cds
-                    else format_plain_row(name, pop, n_rows, seqlen, res, jc))
-            sink.row(text, name, pop)
+            j = i
+            while j < n and events[j][1] == "unit":
+                j += 1
+            run = events[i:j]
+            block = None
+            if not cds and len(run) >= NATIVE_ROWS_MIN and all(isinstance(e[5], int) for e in run):
+                block = format_plain_rows_native([(e[2], e[3], e[4], e[5], _fields(e[6])) for e in run], jc)
+            if block is not None and sink.bulk_ok():
+                sink.rows(block)
+            else:
+                rows = block.split("\n") if block is not None else None
+                for k, e in enumerate(run):
+                    _, _, name, pop, n_rows, seqlen, res, syn = e
+                    text = rows[k] if rows is not None else (
+                        format_cds_row(name, pop, n_rows, seqlen, res, syn, jc) if cds
+                        else format_plain_row(name, pop, n_rows, seqlen, res, jc))
+                    sink.row(text, name, pop)
+            i = j
     sink.flush()
 
 

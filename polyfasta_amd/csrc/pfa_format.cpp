@@ -1,0 +1,152 @@
+// pfa_format.cpp — CSV rows of the non-coding scan, formatted natively.
+//
+// print_result.no_header (PolyFastA.py:182-198) prints one row per scan unit with
+// Python's repr() of three doubles; at 10^5 rows per batch that formatting, not the
+// scan, is what the host spends its time on.  This file reproduces, bit for bit:
+//   * polymorphism()           PolyFastA.py:502-520  (same expressions, same operand order:
+//                              every intermediate is an IEEE double, as in CPython)
+//   * repr(float)              the shortest digit string that round-trips
+//                              (std::to_chars), laid out by CPython's rule: fixed
+//                              notation for 1e-4 <= |x| < 1e16, else d.ddde+XX with at
+//                              least two exponent digits; ".0" appended to integers
+// Rows the reference would answer with a traceback (math domain errors) are not
+// formatted here: the call reports the first such row and the caller takes the Python path.
+#include <charconv>
+#include <cmath>
+#include <cstring>
+
+#include "pfa_common.h"
+
+namespace pfa {
+
+// repr(x) of CPython 3 (float_repr_style == "short"); returns the length written (<= 32)
+static int repr_double(double x, char* out) {
+  if (std::isnan(x)) { memcpy(out, "nan", 3); return 3; }
+  if (std::isinf(x)) { const char* s = x < 0 ? "-inf" : "inf"; const int n = (int)strlen(s); memcpy(out, s, n); return n; }
+  char* o = out;
+  if (std::signbit(x)) { *o++ = '-'; x = -x; }
+  if (x == 0.0) { memcpy(o, "0.0", 3); return int(o - out) + 3; }
+  char sci[40];
+  const auto r = std::to_chars(sci, sci + sizeof(sci), x, std::chars_format::scientific);   // d[.ddd]e[+-]XX, shortest
+  // split into digits and decimal exponent
+  char digits[24];
+  int nd = 0;
+  const char* p = sci;
+  for (; p < r.ptr && *p != 'e'; ++p)
+    if (*p != '.') digits[nd++] = *p;
+  ++p;   // 'e'
+  const bool eneg = *p == '-';
+  ++p;
+  int e10 = 0;
+  for (; p < r.ptr; ++p) e10 = e10 * 10 + (*p - '0');
+  if (eneg) e10 = -e10;
+  const int decpt = e10 + 1;   // position of the decimal point relative to the digit string
+  if (decpt > -4 && decpt <= 16) {   // fixed notation
+    if (decpt <= 0) {
+      *o++ = '0';
+      *o++ = '.';
+      for (int i = 0; i < -decpt; ++i) *o++ = '0';
+      memcpy(o, digits, nd);
+      o += nd;
+    } else if (decpt >= nd) {
+      memcpy(o, digits, nd);
+      o += nd;
+      for (int i = nd; i < decpt; ++i) *o++ = '0';
+      *o++ = '.';
+      *o++ = '0';
+    } else {
+      memcpy(o, digits, decpt);
+      o += decpt;
+      *o++ = '.';
+      memcpy(o, digits + decpt, nd - decpt);
+      o += nd - decpt;
+    }
+  } else {   // exponent notation
+    *o++ = digits[0];
+    if (nd > 1) {
+      *o++ = '.';
+      memcpy(o, digits + 1, nd - 1);
+      o += nd - 1;
+    }
+    *o++ = 'e';
+    int e = decpt - 1;
+    *o++ = e < 0 ? '-' : '+';
+    if (e < 0) e = -e;
+    char eb[8];
+    int ne = 0;
+    do { eb[ne++] = char('0' + e % 10); e /= 10; } while (e);
+    if (ne < 2) eb[ne++] = '0';
+    while (ne) *o++ = eb[--ne];
+  }
+  return int(o - out);
+}
+
+static int put_u64(unsigned long long v, char* out) {
+  const auto r = std::to_chars(out, out + 24, v);
+  return int(r.ptr - out);
+}
+
+}  // namespace pfa
+
+extern "C" {
+
+int pfa_format_double(double x, char* out32) {
+  if (!out32) { pfa::set_error("pfa_format_double: out is NULL"); return PFA_ERR_ARG; }
+  return pfa::repr_double(x, out32);
+}
+
+int64_t pfa_format_plain_rows(const char* prefix_blob, const uint64_t* prefix_off, uint32_t n,
+                              const uint32_t* seg_sites, const uint64_t* h_sum, const uint32_t* n_rows, const double* seqlen,
+                              const double* a1, const double* e1, const double* e2, int jc,
+                              char* out, uint64_t cap, int64_t* bad_row) {
+  if (bad_row) *bad_row = -1;
+  if (n && (!prefix_blob || !prefix_off || !seg_sites || !h_sum || !n_rows || !seqlen || !a1 || !e1 || !e2 || !out)) {
+    pfa::set_error("pfa_format_plain_rows: NULL argument");
+    return PFA_ERR_ARG;
+  }
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint64_t plen = prefix_off[i + 1] - prefix_off[i];
+    if (w + plen + 128u > cap) { pfa::set_error("pfa_format_plain_rows: output capacity %llu too small", (unsigned long long)cap); return PFA_ERR_ARG; }
+    memcpy(out + w, prefix_blob + prefix_off[i], plen);   // "file,seqlen,pop,N,"
+    w += plen;
+    const unsigned long long S = seg_sites[i];
+    if (S == 0) {                                          // PolyFastA.py:503-504, 436-437
+      memcpy(out + w, "0,0,0,NA\n", 9);
+      w += 9;
+      continue;
+    }
+    const double ss = (double)S;
+    // polymorphism(), PolyFastA.py:505-520
+    const double th_pi = (double)h_sum[i] / (double)((unsigned long long)n_rows[i] * (n_rows[i] - 1u));
+    const double th_wa = ss / a1[i];
+    const double rad = (e1[i] * ss) + (e2[i] * ss * (double)(S - 1ull));   // PolyFastA.py:534
+    if (!(rad >= 0.0) || n_rows[i] < 2u) {   // math.sqrt would raise: the caller formats this batch in Python
+      if (bad_row) *bad_row = i;
+      pfa::set_error("pfa_format_plain_rows: row %u has no finite Tajima's D denominator", i);
+      return PFA_ERR_ARG;
+    }
+    const double sd = std::sqrt(rad);
+    double pi_site = th_pi / seqlen[i];
+    if (jc) {                                              // PolyFastA.py:512-516 (bare except -> uncorrected value)
+      const double arg = 1.0 - (4.0 / 3.0) * pi_site;
+      if (arg > 0.0) pi_site = -0.75 * std::log(arg);
+    }
+    w += pfa::put_u64(S, out + w);
+    out[w++] = ',';
+    w += pfa::repr_double(pi_site, out + w);
+    out[w++] = ',';
+    w += pfa::repr_double(th_wa / seqlen[i], out + w);
+    out[w++] = ',';
+    if (sd == 0.0) {                                       // ZeroDivisionError -> "NA" (PolyFastA.py:508-511)
+      out[w++] = 'N';
+      out[w++] = 'A';
+    } else {
+      w += pfa::repr_double((th_pi - th_wa) / sd, out + w);
+    }
+    out[w++] = '\n';
+  }
+  return (int64_t)w;
+}
+
+}  // extern "C"

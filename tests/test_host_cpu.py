@@ -207,3 +207,71 @@ def test_fasta_packer_differential_vs_oracle_reader():
             assert got is None, repr(text)
         else:
             assert got is not None and got.to_dict() == want, (repr(text), got.to_dict() if got else None, want)
+
+
+def test_native_repr_matches_python():
+    """pfa_format_double == repr(float) (CPython 'short' style) on edge cases and random bit patterns."""
+    import ctypes
+    import random
+    import struct
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(40)
+
+    def fmt(x):
+        n = lib.pfa_format_double(ctypes.c_double(x), buf)
+        return buf.raw[:n].decode()
+
+    rnd = random.Random(11)
+    xs = [0.0, -0.0, 1.0, -1.0, 1e16, 1e15, 9999999999999998.0, 123456789012345678.0, 1e-4, 9.999e-5, 1e-5, 5e-324,
+          2.2250738585072014e-308, 1.7976931348623157e308, float("inf"), float("-inf"), float("nan"), 0.1, 1 / 3, 1e22, 1e23,
+          0.01410000000000001, -1.7406412034629681, 100.0, 1234.5]
+    xs += [struct.unpack("<d", struct.pack("<Q", rnd.getrandbits(64)))[0] for _ in range(60000)]
+    xs += [rnd.uniform(-1, 1) * 10 ** rnd.randint(-20, 20) for _ in range(40000)]
+    xs += [float(rnd.randint(0, 10 ** rnd.randint(1, 18))) for _ in range(20000)]
+    for x in xs:
+        assert fmt(x) == repr(x), (repr(x), fmt(x))
+
+
+def test_native_rows_match_python_rows():
+    """pfa_format_plain_rows == format_plain_row (and through it PolyFastA.py:182-198, 502-520),
+    including units without variable sites, D = NA for N = 2 and 3, and --jc with its fallback."""
+    rng = np.random.default_rng(21)
+    M = 20000
+    nrows = rng.choice([2, 3, 4, 5, 20, 50, 100, 200, 1000], M)
+    seg = rng.integers(0, 600, M)
+    seg[rng.random(M) < 0.1] = 0
+    units = []
+    for i in range(M):
+        n, s = int(nrows[i]), int(seg[i])
+        h = 0 if s == 0 else int(rng.integers(1, max(2, n * n // 2))) * s
+        rec = (h, 0, 0, s, 0, 0, 0, 0, 0, 0, 0)
+        units.append((f"aln{i}.fa" if i % 7 else f"dir/é{i}.fa", "NA" if i % 3 else f"pop{i % 5}", n,
+                      int(rng.choice([1, 2, 3, 1000, 10000, 123457])), rec))
+    for jc in (False, True):
+        want = "".join(cli.format_plain_row(u[0], u[1], u[2], u[3], u[4], jc) + "\n" for u in units)
+        assert cli.format_plain_rows_native(units, jc) == want
+    # pi/site >= 0.75: the Jukes-Cantor logarithm fails and the uncorrected value is printed (:512-516)
+    u = [("x.fa", "NA", 4, 1, (12, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0))]
+    assert cli.format_plain_rows_native(u, True) == cli.format_plain_row(*u[0][:4], u[0][4], True) + "\n"
+
+
+def test_emit_uses_native_rows_transparently(tmp_path, capsys):
+    rng = np.random.default_rng(3)
+    events = []
+    for i in range(300):
+        if i % 50 == 7:
+            events.append((i, "comment", f"# Sequences do not have the same length: f{i}.fa"))
+            continue
+        s = int(rng.integers(0, 50))
+        events.append((i, "unit", f"f{i}.fa", "NA", 20, 1000, (0 if s == 0 else 37 * s, 0, 0, s, 0, 0, 0, 0, 0, 0, 0), None))
+    want = []
+    for ev in events:
+        want.append(ev[2] if ev[1] == "comment" else cli.format_plain_row(ev[2], ev[3], ev[4], ev[5], ev[6], False))
+    out = tmp_path / "o.csv"
+    cli.emit(events, cli.Sink(str(out), True), False, False)
+    assert out.read_text() == "\n".join(want) + "\n"
+    cli.emit(events, cli.Sink("", True), False, False)
+    assert capsys.readouterr().out == "\n".join(want) + "\n"
+    out2 = tmp_path / "o2.csv"
+    cli.emit(events, cli.Sink(str(out2), False), False, False)      # progress chatter per row: row-by-row path
+    assert out2.read_text() == "\n".join(want) + "\n"
