@@ -128,6 +128,10 @@ int pfa_sync(void);
 int pfa_dev_alloc(size_t bytes, void** out);
 int pfa_dev_free(void* p);
 int pfa_upload(void* dst_dev, const void* src_host, size_t bytes);
+/* enqueue the copy on the context stream and return: `src_host` (pinned memory from
+ * pfa_host_alloc for a truly asynchronous copy) must stay untouched until pfa_sync() or a
+ * pfa_plan_fetch() has returned; scans enqueued afterwards see the uploaded bytes */
+int pfa_upload_async(void* dst_dev, const void* src_host, size_t bytes);
 int pfa_download(void* dst_host, const void* src_dev, size_t bytes);
 
 /* ---- scan plans ------------------------------------------------------------

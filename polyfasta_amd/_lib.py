@@ -84,6 +84,7 @@ _PROTOTYPES = {
     "pfa_dev_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "pfa_dev_free": (ctypes.c_int, [_vp]),
     "pfa_upload": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "pfa_upload_async": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     "pfa_download": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     "pfa_tile_sites": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_uint32]),
     "pfa_var_words_per_tile": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_uint32]),

@@ -165,20 +165,28 @@ def build_parser():
     return p
 
 
-def _scan_table(bases, used, descs, row_idx):
-    """Upload the packed bases, scan every unit, return the ScanOutput."""
+_device_cache = [None]
+
+
+def _device_buffer(nbytes):
+    """One device buffer for the ingest batches of this process (a batch is scanned and its
+    records fetched before the next one is uploaded), grown on demand."""
+    if _device_cache[0] is None or _device_cache[0].nbytes < nbytes:
+        if _device_cache[0] is not None:
+            _device_cache[0].free()
+        _device_cache[0] = DeviceBuffer(max(int(nbytes), 16))
+    return _device_cache[0]
+
+
+def _scan_uploaded(dev, used, descs, row_idx):
+    """Scan every unit of a batch whose bases are already on their way to `dev`."""
     table = finalize_layout(descs, row_idx, used)
-    dev = DeviceBuffer(max(used, 16))
+    plan = Plan(table)
     try:
-        dev.upload(bases[:used])
-        plan = Plan(table)
-        try:
-            plan.run(dev)
-            return plan.fetch()
-        finally:
-            plan.close()
+        plan.run(dev)
+        return plan.fetch()          # synchronises the stream: upload, scan and record copy are done
     finally:
-        dev.free()
+        plan.close()
 
 
 def _events_for(fidx, path, name, status, names, n_rows, seqlen, args, add_unit):
@@ -261,14 +269,19 @@ def process_files(indexed_paths, args):
         fut = pool.submit(load, first, slot) if first else None
         while fut is not None:
             chunk, pinned, (info, names, used) = fut.result()
-            nxt = next_chunk(BATCH_BYTES)
-            fut = pool.submit(load, nxt, 1 - slot) if nxt else None      # ingest of the next batch overlaps this one's scan
-            bases = pinned.array
             status = info["status"]
             if (status == PFA_ERR_IO).any():
                 path = chunk[int(np.flatnonzero(status == PFA_ERR_IO)[0])][1]
                 open(path, "rb").close()          # raises the OSError the reference would raise (:239)
                 raise OSError(f"cannot read {path}")
+            dev = None
+            if used and (status == 0).any():
+                # the H2D copy starts now and runs under the host work below (next ingest request,
+                # descriptor table, plan); the pinned buffer is not touched again before the fetch
+                dev = _device_buffer(used)
+                dev.upload_async(pinned.array[:used])
+            nxt = next_chunk(BATCH_BYTES)
+            fut = pool.submit(load, nxt, 1 - slot) if nxt else None      # ingest of the next batch overlaps this one's scan
             deferred = [chunk[k] for k in np.flatnonzero(status == PFA_FILE_DEFERRED)]
             descs, ridx, pending = [], None, []
             if not args.pops:
@@ -308,7 +321,13 @@ def process_files(indexed_paths, args):
                                            int(fi["n_sites"]), args, add_unit)
                 descs = np.array(dl, dtype=DESC_DTYPE) if dl else []
                 ridx = np.concatenate(rl) if rl else None
-            out = _scan_table(bases, used, descs, ridx) if len(descs) else None
+            if len(descs):
+                out = _scan_uploaded(dev, used, descs, ridx)
+            else:
+                out = None
+                if dev is not None:
+                    from . import _lib
+                    _lib.check(_lib.load().pfa_sync())
             _attach(pending, out, done)
             if deferred:
                 if len(deferred) == len(chunk):

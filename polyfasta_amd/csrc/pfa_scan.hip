@@ -1205,6 +1205,13 @@ int pfa_upload(void* dst_dev, const void* src_host, size_t bytes) {
   return PFA_OK;
 }
 
+int pfa_upload_async(void* dst_dev, const void* src_host, size_t bytes) {
+  PFA_NEED_INIT();
+  if (!bytes) return PFA_OK;
+  PFA_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, pfa::ctx().stream));
+  return PFA_OK;
+}
+
 int pfa_download(void* dst_host, const void* src_dev, size_t bytes) {
   PFA_NEED_INIT();
   if (!bytes) return PFA_OK;

@@ -41,6 +41,12 @@ class DeviceBuffer:
         assert offset + a.nbytes <= self.nbytes
         _lib.check(_lib.load().pfa_upload(ctypes.c_void_p(self.ptr.value + offset), _lib.ptr(a), a.nbytes))
 
+    def upload_async(self, arr: np.ndarray, offset: int = 0):
+        """Enqueue the copy and return; `arr` (pinned memory) must stay untouched until the
+        next fetch or pfa_sync()."""
+        assert arr.flags["C_CONTIGUOUS"] and offset + arr.nbytes <= self.nbytes
+        _lib.check(_lib.load().pfa_upload_async(ctypes.c_void_p(self.ptr.value + offset), _lib.ptr(arr), arr.nbytes))
+
     def download(self, nbytes: int = None, offset: int = 0) -> np.ndarray:
         nbytes = self.nbytes - offset if nbytes is None else nbytes
         out = np.empty(nbytes, dtype=np.uint8)
