@@ -129,10 +129,13 @@ struct TallLayout {
 
 PFA_HD inline TallLayout tall_layout(uint32_t rows_per_chunk, uint32_t max_slots, uint32_t hist_bins) {
   TallLayout o;
-  o.tile = 0;                                   // R x 256 bytes; reused at the end of a tile for the
-  o.list = round16(rows_per_chunk * 256u);      //   256-bin column histogram (1 KiB) + its site list (256 B)
-  o.cnt = o.list + max_slots * 4u;              // list: per slot  x | d << 8 | mode << 16 | site << 24
-  o.hist = o.cnt + max_slots * 24u;             // cnt: six u32 counters per slot (two-allele mode uses two)
+  o.tile = 0;                                   // R x 256 bytes
+  o.list = round16(rows_per_chunk * 256u);      // list: per slot  x | d << 8 | mode << 16 | site << 24
+  o.cnt = o.list + max_slots * 4u;              // cnt: six u32 counters per slot (two-allele mode uses two)
+  // Once the slots of a tile have been turned into H and SFS, list + cnt are reused for the
+  // column path: its site list (256 B at `list`) and its 256-bin histogram (1 KiB behind it).
+  const uint32_t slots_bytes = max_slots * 28u;
+  o.hist = o.list + (slots_bytes > 1280u ? slots_bytes : 1280u);
   o.total = o.hist + round16(hist_bins * 4u + 4u);
   return o;
 }
@@ -730,8 +733,8 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   uint32_t* const list = reinterpret_cast<uint32_t*>(lds + lo.list);
   uint32_t* const cnt = reinterpret_cast<uint32_t*>(lds + lo.cnt);
   uint32_t* const hist = reinterpret_cast<uint32_t*>(lds + lo.hist);
-  uint32_t* const colhist = reinterpret_cast<uint32_t*>(tile8);   // 256 bins, end-of-tile only
-  uint8_t* const xlist = tile8 + 1024u;                           // sites for the column path
+  uint8_t* const xlist = lds + lo.list;                                      // end of tile: sites for the column path
+  uint32_t* const colhist = reinterpret_cast<uint32_t*>(lds + lo.list + 256u);   // and its 256 bins
 
   const uint32_t nbins = N / 2u, HB = umin(nbins, A.hist_bins);
   const bool mapped = D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
@@ -757,11 +760,32 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     else atomicAdd(&A.sfs[D.sfs_off + second - 1u], 1u);
   };
 
+  // ---------------- stage rows [r0, r0 + Rc) x 256 sites of a tile (asynchronous for LDS-DMA)
+  const uint32_t c16 = lane % 16u, rr = lane / 16u;
+  auto stage_chunk = [&](uint32_t tile, uint32_t r0, uint32_t idx_rows) {
+    const uint32_t Rc = umin(R, N - r0);
+    const uint32_t col = umin(tile * TW + 16u * c16, D.row_stride - 16u);
+    const uint32_t n_inst = (Rc + 3u) / 4u;
+    for (uint32_t g = 0; g < n_inst; ++g) {
+      const uint32_t r = 4u * g + rr;
+      const uint32_t row = mapped ? (uint32_t)__shfl((int)idx_rows, (int)(r & 63u)) : r0 + r;
+      if (r < Rc) {
+        const uint8_t* src = mat + (uint64_t)row * D.row_stride + col;
+        if constexpr (STAGE == 1)
+          *reinterpret_cast<uint4*>(tile8 + g * 1024u + lane * 16u) = *reinterpret_cast<const uint4*>(src);
+        else
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
+      }
+    }
+  };
+  // A chunk is requested as soon as the previous one has been read for the last time: the next
+  // chunk of the tile, or the first chunk of the next tile — whose loads then run under the
+  // end-of-tile work (H, SFS, column path), which touches only the slot tables.
+  stage_chunk(t0, 0u, idx_cur);
+
   for (uint32_t tile = t0; tile < t1; ++tile) {
     const uint32_t site0 = tile * TW;
     const uint32_t lim = umin(TW, L - site0);
-    const uint32_t c16 = lane % 16u, rr = lane / 16u;
-    const uint32_t col = umin(site0 + 16u * c16, D.row_stride - 16u);
     uint32_t va = 0xFFFFFFFFu, vo = 0u, vd = 0u;   // running AND / OR / XOR words of the rows seen so far
     uint32_t P = 0u, ovf = 0u;                     // variable sites so far; own sites that found no slot
 
@@ -771,19 +795,6 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       if (mapped && multi) {
         const uint32_t r0n = r0 + R < N ? r0 + R : 0u;
         if (lane < umin(R, N - r0n)) idx_nxt = ridx[r0n + lane];
-      }
-      // ---------------- stage Rc rows x 256 sites
-      const uint32_t n_inst = (Rc + 3u) / 4u;
-      for (uint32_t g = 0; g < n_inst; ++g) {
-        const uint32_t r = 4u * g + rr;
-        const uint32_t row = mapped ? (uint32_t)__shfl((int)idx_cur, (int)(r & 63u)) : r0 + r;
-        if (r < Rc) {
-          const uint8_t* src = mat + (uint64_t)row * D.row_stride + col;
-          if constexpr (STAGE == 1)
-            *reinterpret_cast<uint4*>(tile8 + g * 1024u + lane * 16u) = *reinterpret_cast<const uint4*>(src);
-          else
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
-        }
       }
       if constexpr (STAGE != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -899,8 +910,10 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
           }
         }
       }
-      __syncthreads();   // the tile buffer is reused by the next chunk
+      __syncthreads();   // the tile buffer has been read for the last time
       idx_cur = idx_nxt;
+      if (r0 + R < N) stage_chunk(tile, r0 + R, idx_cur);
+      else if (tile + 1u < t1) stage_chunk(tile + 1u, 0u, idx_cur);
     }
 
     // ---------------- end of tile: S, bitmap, H and SFS of the slotted sites
