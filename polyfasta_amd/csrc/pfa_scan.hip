@@ -1038,9 +1038,9 @@ __global__ void __launch_bounds__(256) slab_to_host_kernel(const uint4* __restri
 
 // ---------------------------------------------------------------- plans
 static constexpr uint32_t kMaxRowsWide = 600u;  // coding plans: LB = 4 (256-site tiles) up to here, LB = 1 above
-static constexpr uint32_t kTallMin = 64u;       // non-coding plans with more rows than this: scan_tall_kernel
+static constexpr uint32_t kLdsPerCu = 160u * 1024u;
 static constexpr uint32_t kTallRows = 48u;      // its rows per chunk (upper bound)
-static constexpr uint32_t kTallSlots = 96u;     // its count-table slots per tile
+static constexpr uint32_t kTallSlots = 64u;     // its count-table slots per tile (measured: 64 6.03, 96 5.68 TB/s at N = 100)
 static constexpr int kEventRing = 64;
 
 }  // namespace pfa
@@ -1342,10 +1342,19 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
   p->n_bases_bytes = n_bases_bytes;
   p->use_rowmap = n_row_idx != 0;
   p->lds_bytes = pfa::lds_layout(lb, n_max, any_cds, p->use_rowmap).total;
-  // Non-coding plans whose largest unit exceeds kTallMin rows run the row-chunked kernel:
-  // equal chunks of at most kTallRows rows (a multiple of 4: one LDS-DMA instruction moves 4 rows).
+  // Non-coding plans with many-row units run the row-chunked kernel.  Keeping all rows of a tile
+  // in LDS is the faster shape while it still fills the CU: at least 5 waves whose tiles add up to
+  // 135 KB of loads in flight (measured: N = 100, 6 waves, 6.45 TB/s against 6.03 row-chunked;
+  // N = 128, 4 waves, 5.84 against 5.88; N = 160, 3 waves, 5.04 against 6.06).
+  // Equal chunks of at most kTallRows rows (a multiple of 4: one LDS-DMA instruction moves 4 rows).
   // PFA_TALL_* environment overrides exist for timing experiments.
-  if (!any_cds && n_max > pfa::env_u32("PFA_TALL_MIN", pfa::kTallMin)) {
+  bool want_tall = false;
+  if (!any_cds && n_max > 64u) {
+    const uint32_t waves = pfa::kLdsPerCu / std::max(p->lds_bytes, 1u);
+    want_tall = waves < 5u || (uint64_t)waves * n_max * 256u < 135000ull;
+  }
+  if (getenv("PFA_TALL_MIN")) want_tall = !any_cds && n_max > pfa::env_u32("PFA_TALL_MIN", 64u);
+  if (want_tall) {
     const uint32_t rcap = std::min(64u, std::max(8u, pfa::env_u32("PFA_TALL_ROWS", pfa::kTallRows)));
     const uint32_t nc = (n_max + rcap - 1u) / rcap;
     p->tall = true;
