@@ -77,7 +77,7 @@ struct Geo {
 };
 
 struct LdsLayout {
-  uint32_t tile, list, hist, rowmap, hsite, carry, cinfo, ainfo, slut, synhist, total;
+  uint32_t tile, list, hist, rowmap, hsite, carry, synhist, total;
 };
 
 PFA_HD inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -91,14 +91,12 @@ PFA_HD inline LdsLayout lds_layout(uint32_t lb, uint32_t n_max, bool cds, bool r
   o.list = round16(n * ww);  // exactly N rows: lanes of the last DMA instruction beyond row N-1 are masked off
   o.hist = o.list + 2u * ww;   // list: the tile's variable sites, ww u16 entries (site | XOR byte << 8)
   o.rowmap = o.hist + round16((n / 2u) * 4u + 4u);
-  // hsite[s]: H | allele mask << 24 of variable site s (written by tier 2; entries of other sites are stale
-  // and never used); hsite[-2], hsite[-1]: the last two sites of the previous tile
+  // hsite[s]: H and allele mask of variable site s (written by tier 2; entries of other sites are stale
+  // and never used): 16 bits (H < 4096 | mask << 12) when no unit has more than 64 rows, else 32
+  // (H | mask << 24); hsite[-2], hsite[-1]: the last two sites of the previous tile
   o.hsite = o.rowmap + (rowmap ? round16(n * 4u) : 0u) + (cds ? 16u : 0u);
-  o.carry = o.hsite + (cds ? ww * 4u : 0u);
-  o.cinfo = o.carry + (cds ? round16(2u * n) : 0u);   // carry: last two columns of the previous tile, per row
-  o.ainfo = o.cinfo + (cds ? 64u : 0u);     // cinfo: per codon, synonymous-neighbour count | stop << 7
-  o.slut = o.ainfo + (cds ? 64u : 0u);      // ainfo: LDS copy of Tables::annot_info
-  o.synhist = o.slut + (cds ? (uint32_t)sizeof(SingleLut) : 0u);   // slut: LDS copy of the single-position table
+  o.carry = o.hsite + (cds ? ww * (n <= 64u ? 2u : 4u) : 0u);
+  o.synhist = o.carry + (cds ? round16(2u * n) : 0u);   // carry: last two columns of the previous tile, per row
   o.total = o.synhist + (cds ? round16(PFA_SYN_BINS * 4u) : 0u);
   return o;
 }
@@ -255,16 +253,32 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   uint16_t* const list = reinterpret_cast<uint16_t*>(lds + lo.list);
   uint32_t* const hist = reinterpret_cast<uint32_t*>(lds + lo.hist);
   uint32_t* const rowmap = reinterpret_cast<uint32_t*>(lds + lo.rowmap);
-  uint32_t* const hsite = reinterpret_cast<uint32_t*>(lds + lo.hsite);
+  uint32_t* const hsite32 = reinterpret_cast<uint32_t*>(lds + lo.hsite);
+  uint16_t* const hsite16 = reinterpret_cast<uint16_t*>(lds + lo.hsite);
+  const bool h16 = A.n_max <= 64u;
+  // H and allele mask of a variable site (tile-relative index, -2 and -1: previous tile), widened to H | mask << 24
+  auto hsite_get = [&](int rel) -> uint32_t {
+    if (h16) { const uint32_t v = hsite16[rel]; return (v & 0xFFFu) | (v >> 12) << 24; }
+    return hsite32[rel];
+  };
   uint8_t* const carry = lds + lo.carry;
-  uint8_t* const cinfo = lds + lo.cinfo;
-  uint8_t* const ainfo = lds + lo.ainfo;
-  uint8_t* const slut = lds + lo.slut;
   uint32_t* const synhist = reinterpret_cast<uint32_t*>(lds + lo.synhist);
 
   // lane c stands for codon c in the wave-uniform classifier
   const uint32_t my_info = HAS_CDS ? d_tables.annot_info[lane] : 0u;
   const unsigned long long my_same = HAS_CDS ? d_tables.same_annot[lane] : 0ull;
+  // small tables live in registers, one entry per lane, and are read with ds_bpermute (the LDS
+  // crossbar, no LDS memory): per codon the synonymous-neighbour count | stop << 7, and the three
+  // 256-byte planes of the single-position table (pfa_codon.h: SingleLut), one word per lane each
+  const uint32_t my_cinfo = HAS_CDS ? (uint32_t)d_tables.syn3[lane] | (uint32_t)((d_tables.stop_mask >> lane) & 1ull) << 7 : 0u;
+  uint32_t my_slut[3] = {0u, 0u, 0u};
+  if constexpr (HAS_CDS) {
+#pragma unroll
+    for (uint32_t pl = 0; pl < 3u; ++pl) my_slut[pl] = reinterpret_cast<const uint32_t*>(d_single_lut.v)[pl * 64u + lane];
+  }
+  auto lane_lookup = [&](uint32_t from_lane, uint32_t mine) -> uint32_t {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)mine);
+  };
   const uint32_t nbins = N / 2u;
   const bool mapped = !LEAN && D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
   if (mapped)
@@ -273,10 +287,6 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   if (cds)
   {
     for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) synhist[i] = 0u;
-    cinfo[lane] = uint8_t(d_tables.syn3[lane] | (((d_tables.stop_mask >> lane) & 1ull) << 7));
-    ainfo[lane] = d_tables.annot_info[lane];
-    for (uint32_t i = lane; i < sizeof(SingleLut) / 4u; i += 64u)
-      reinterpret_cast<uint32_t*>(slut)[i] = reinterpret_cast<const uint32_t*>(d_single_lut.v)[i];
   }
   __syncthreads();
 
@@ -447,7 +457,10 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       if (act && ph == 0u) {
         const uint32_t hs = NN - sumsq;
         acc_H += hs;
-        if (cds) hsite[s] = hs | pres << 24;   // H of the site + which of A, C, T, G occur there (bits 24-27, codon base order)
+        if (cds) {   // H of the site + which of A, C, T, G occur there (codon base order)
+          if (h16) hsite16[s] = uint16_t(hs | pres << 12);
+          else hsite32[s] = hs | pres << 24;
+        }
         if (second == 0u) acc_bad += 1u;
         else atomicAdd(&hist[second - 1u], 1u);
       }
@@ -558,7 +571,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
               for (uint32_t p = 0; p < 3u; ++p) {
                 const bool is_s = (labels >> p) & 1u, is_n = (labels >> (3u + p)) & 1u;
                 if (is_s || is_n) {
-                  const uint32_t hs = hsite[rel + (int)p] & 0xFFFFFFu;
+                  const uint32_t hs = hsite_get(rel + (int)p) & 0xFFFFFFu;
                   if (is_s) { acc_segS += 1u; acc_HS += hs; }
                   else { acc_segN += 1u; acc_HN += hs; }
                   if (!LEAN && A.syn_bm != nullptr) mark_site(is_s, rel + (int)p);
@@ -582,14 +595,16 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       // is clean iff it equals it), then one LUT read: synonymous weight | stop << 7
 #pragma unroll
       for (uint32_t it = 0; it < NIT; ++it) {
+        // (every lane computes and looks up, so that the ds_bpermute runs with all lanes enabled:
+        // a disabled lane would not supply its table entry)
+        const uint32_t w = xw[it];
+        const uint32_t t2 = w & 0x060606u;
+        const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
+        const uint32_t bad = (0x414141u + t2 + (e2 << 4) - e2) ^ w;
+        const uint32_t tt = t2 >> 1;
+        const uint32_t ci = lane_lookup(((tt & 3u) << 4) | ((tt >> 6) & 0xCu) | ((tt >> 16) & 3u), my_cinfo);
         if (mono[it]) {
-          const uint32_t w = xw[it];
-          const uint32_t t2 = w & 0x060606u;
-          const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
-          const uint32_t bad = (0x414141u + t2 + (e2 << 4) - e2) ^ w;
           if (bad == 0u) {
-            const uint32_t tt = t2 >> 1;
-            const uint32_t ci = cinfo[((tt & 3u) << 4) | ((tt >> 6) & 0xCu) | ((tt >> 16) & 3u)];
             acc_syn1 += ci & 7u;
             acc_stops += ci >> 7;
           } else {
@@ -603,20 +618,25 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       // another symbol there hold an unclean codon and drop out, PolyFastA.py:301).  Only that
       // position can be labelled.  The two fixed bytes are the lane's consensus bytes; the
       // allele mask and H of the variable site come from tier 2 (hsite).
-      auto single_col = [&](uint32_t w, uint32_t p, int end_rel) {
-        const int rel = end_rel - 2;
-        const uint32_t hv = hsite[rel + (int)p];
-        const uint32_t am = hv >> 24;
+      // (All lanes run it, `valid` marks the lanes that own such a column: the table reads are
+      // ds_bpermute's and need every lane enabled.)
+      auto single_col = [&](bool valid, uint32_t w, uint32_t p, int end_rel) {
+        const int rel = valid ? end_rel - 2 : 0;
+        const uint32_t hv = hsite_get(rel + (int)p);
+        const uint32_t am = valid ? hv >> 24 : 0u;
         // exactly-A/C/G/T test of the two fixed bytes (as above; the byte of position p is meaningless)
         const uint32_t t2 = w & 0x060606u;
         const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
         const uint32_t bad = ((0x414141u + t2 + (e2 << 4) - e2) ^ w) & ~(0xFFu << (8u * p));
         const uint32_t k = bad ? 0u : (uint32_t)__popc(am);   // distinct clean codons
-        if (k == 0u) { acc_missing += 1u; return; }
         const uint32_t tt = t2 >> 1;
         const uint32_t c0 = tt & 3u, c1 = (tt >> 8) & 3u, c2 = (tt >> 16) & 3u;
         const uint32_t b4 = p == 0u ? (c1 << 2 | c2) : p == 1u ? (c0 << 2 | c2) : (c0 << 2 | c1);
-        const uint32_t v = slut[(p * 16u + b4) * 16u + am];
+        const uint32_t j = b4 * 16u + (am & 15u);             // entry of plane p
+        const uint32_t w0 = lane_lookup(j >> 2, my_slut[0]), w1 = lane_lookup(j >> 2, my_slut[1]), w2 = lane_lookup(j >> 2, my_slut[2]);
+        const uint32_t v = ((p == 0u ? w0 : p == 1u ? w1 : w2) >> (8u * (j & 3u))) & 0xFFu;
+        if (!valid) return;
+        if (k == 0u) { acc_missing += 1u; return; }
         const uint32_t t3 = v & 0x1Fu;
         if (k == 1u) acc_syn1 += t3;
         else atomicAdd(&synhist[k], t3);
@@ -630,22 +650,21 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       {
         const bool any1 = single[0] || single[1];
         if (__any(any1)) {
-          if (any1) {
-            const uint32_t sel = single[0] ? 0u : 1u;
-            single_col(sel ? xw[1] : xw[0], sel ? pv[1] : pv[0], sel ? endo[1] : endo[0]);
-          }
+          const uint32_t sel = single[0] ? 0u : 1u;
+          single_col(any1, sel ? xw[1] : xw[0], (sel ? pv[1] : pv[0]) % 3u, sel ? endo[1] : endo[0]);
         }
         const bool both = single[0] && single[1];            // a lane owning two such columns: rare
-        if (__any(both)) {
-          if (both) single_col(xw[1], pv[1], endo[1]);
-        }
+        if (__any(both)) single_col(both, xw[1], pv[1] % 3u, endo[1]);
       }
       // the trailing 1-2 sites of an alignment whose length is not a multiple of 3 never form
       // a clean codon (PolyFastA.py:301-305)
       if (tile + 1u == n_tiles && (L % 3u) != 0u && lane == 0u) acc_missing += 1u;
 
       // H of the last two sites, for the codons that straddle into the next tile
-      if (lane < 2u) hsite[(int)lane - 2] = hsite[G::WW - 2u + lane];
+      if (lane < 2u) {
+        if (h16) hsite16[(int)lane - 2] = hsite16[G::WW - 2u + lane];
+        else hsite32[(int)lane - 2] = hsite32[G::WW - 2u + lane];
+      }
     } else {
       __syncthreads();   // every read of the tile buffer is done: request the next tile
       if (tile + 1u < t1) stage(tile + 1u);
