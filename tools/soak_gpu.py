@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""One-off soak: the randomised parity cases of tests/test_gpu_random.py over many more seeds
+(general and lean instantiations, coding and non-coding, row subsets, odd alphabets)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import c_oracle
+from polyfasta_amd import _lib, scan, stats
+from tests import test_gpu_random as T
+_lib.init(0)
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+t0 = time.time()
+units_checked = 0
+for seed in range(1000, 1000 + n_seeds):
+    rng = np.random.default_rng(seed)
+    lean = seed % 2 == 0
+    b = scan.Batch(stride_align=int(rng.choice([16, 32, 64, 128, 256])))
+    units = []
+    for _ in range(80):
+        n = int(rng.choice([1, 2, 3, 4, 5, 8, 17, 33, 50, 63, 64] + ([] if lean else [65, 100, 129, 300])))
+        L = int(rng.choice([1, 2, 3, 4, 15, 16, 17, 47, 255, 256, 257, 258, 259, 511, 512, 513, 767, 768, 769, 770, 771, 1000, 1537, 2305, 3001, 9000]))
+        alpha = T.ALPHABETS[int(rng.integers(0, len(T.ALPHABETS)))]
+        m = T._random_matrix(rng, n, L, alpha, float(rng.choice([0.0, 0.001, 0.01, 0.02, 0.05, 0.3])))
+        mid = b.add_matrix(m)
+        cds = bool(rng.random() < 0.7)
+        b.add_unit(mid, cds=cds)
+        units.append((m, None, cds))
+        if not lean and n >= 3 and rng.random() < 0.5:
+            rows = rng.permutation(n)[: int(rng.integers(1, n + 1))].astype(np.uint32)
+            b.add_unit(mid, rows=rows, cds=cds)
+            units.append((m, rows, cds))
+    out = scan.scan_batch(b, want_pos=not lean, want_sn=not lean)
+    for i, (m, rows, cds) in enumerate(units):
+        o = c_oracle.scan(m, rows=rows, cds=cds, want_sites=not lean)
+        if lean:
+            r = out.results[i]
+            assert (int(r["seg_sites"]), int(r["H"]), int(r["sfs_bad"])) == (o["S"], o["H"], o["sfs_bad"]), (seed, i, m.shape)
+            assert out.sfs(i).tolist() == o["sfs"].tolist(), (seed, i)
+            if cds:
+                assert (int(r["seg_S"]), int(r["seg_N"]), int(r["H_S"]), int(r["H_N"]), int(r["nstops"]), int(r["missing_cols"])) == \
+                       (o["seg_S"], o["seg_N"], o["H_S"], o["H_N"], o["nstops"], o["missing_cols"]), (seed, i, m.shape)
+                assert abs(stats.syn_sites_from_bins(out.syn_num[i]) - o["count_syn"]) <= 1e-9 * max(1.0, o["count_syn"])
+        else:
+            T._compare(out, i, o, cds)
+        units_checked += 1
+    print(f"seed {seed} ok ({'lean' if lean else 'general'}, {len(units)} units)", flush=True)
+print(f"soak: {units_checked} units over {n_seeds} seeds identical to the oracle in {time.time() - t0:.0f} s")
