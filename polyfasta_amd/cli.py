@@ -474,8 +474,14 @@ def main(argv=None):
     if len(args.file) > 0 and args.pipe and not (args.file[0] == "stdin" or args.file[0] == args.name):
         parser.error("A FASTA file or multiple files cannot be used with the --pipe argument.")   # :105-106
 
+    from . import _lib
     from .dist import Group, env_world, shard_indices
     rank, _, world = env_world()
+    try:                                   # the scan runs on the GPU or not at all: say so before any output
+        _lib.init()                        # LOCAL_RANK modulo the visible devices
+    except (_lib.PfaError, _lib.PfaLibraryError) as e:
+        print(f"polyfasta_amd: {e}", file=sys.stderr)
+        return 2
     group = Group() if (world > 1 or os.environ.get("PFA_FORCE_DIST")) else None
 
     sink = Sink(args.out, args.silent)
