@@ -15,9 +15,10 @@
 #include <cmath>
 #include <cstring>
 
-#include "pfa_common.h"
+#include "../../include/pfa.h"
 
 namespace pfa {
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
 // repr(x) of CPython 3 (float_repr_style == "short"); returns the length written (<= 32)
 static int repr_double(double x, char* out) {

@@ -1395,6 +1395,7 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
   // 6.48 TB/s; 20 tiles 6.36, 4 tiles 6.36, 1 tile 5.43)
   const uint64_t target_blocks = (uint64_t)std::max(pfa::ctx().n_cu, 1) * 96ull;
   uint64_t tpc = std::max<uint64_t>(1, sum_tiles / target_blocks);
+  if (getenv("PFA_TILES_PER_CHUNK")) tpc = std::max(1u, pfa::env_u32("PFA_TILES_PER_CHUNK", 10u));   // timing experiments
   tpc = std::min<uint64_t>(tpc, std::max<uint32_t>(max_tiles, 1));
   tpc = std::max<uint64_t>(tpc, ((uint64_t)max_tiles + 65534ull) / 65535ull);
   p->n_chunks = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)max_tiles + tpc - 1) / tpc));

@@ -1,0 +1,172 @@
+// host_fuzz.cpp — sanitizer harness for the HOST code of libpfa_hip.so (test infrastructure).
+// Built by tests/test_host_sanitizers.py with plain g++ -fsanitize=address,undefined from
+// csrc/pfa_fasta.cpp + csrc/pfa_format.cpp (no HIP needed) and run on random FASTA-like
+// byte strings, truncated inputs, files on disk and random row tables: the packer reads
+// arbitrary user files, so every out-of-bounds access there is a bug whatever the return code.
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+#include "../include/pfa.h"
+
+// the two symbols the host translation units expect from pfa_scan.hip
+static thread_local char g_err[512];
+namespace pfa {
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace pfa
+extern "C" const char* pfa_last_error(void) { return g_err; }
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() {
+  uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static uint32_t below(uint32_t n) { return n ? uint32_t(rnd() % n) : 0u; }
+
+static std::string random_fasta() {
+  static const char* eols[] = {"\n", "\r\n", "\r", "\n\n", " \n", "\t\r\n"};
+  static const char alphabet[] = "ACGTacgtNn-RYKM?*. \t";
+  std::string s;
+  const uint32_t style = below(8);
+  if (style == 0) s += "junk before\n";
+  if (style == 1) return std::string(below(40), char(below(256)));
+  const uint32_t n_rec = below(7);
+  for (uint32_t r = 0; r < n_rec; ++r) {
+    s += '>';
+    if (below(6)) s += "seq" + std::to_string(below(4));          // duplicates on purpose
+    if (below(9) == 0) s += char(128 + below(128));
+    s += eols[below(6)];
+    const uint32_t n_lines = below(4);
+    for (uint32_t l = 0; l < n_lines; ++l) {
+      const uint32_t len = below(4) ? below(70) : below(3);
+      for (uint32_t k = 0; k < len; ++k) s += (below(300) == 0) ? char(128 + below(128)) : alphabet[below(sizeof(alphabet) - 1)];
+      if (r + 1 < n_rec || l + 1 < n_lines || below(2)) s += eols[below(6)];
+    }
+  }
+  if (style == 2 && !s.empty()) s.resize(below((uint32_t)s.size()));   // truncated anywhere
+  return s;
+}
+
+static void fuzz_text(const std::string& s) {
+  // exact-size heap copy: ASan sees any read past the end
+  uint8_t* text = (uint8_t*)malloc(s.size() ? s.size() : 1);
+  memcpy(text, s.data(), s.size());
+  const int64_t n = pfa_fasta_index(s.size() ? text : nullptr, s.size(), nullptr, 0);
+  if (n > 0) {
+    std::vector<pfa_fasta_rec> recs((size_t)n);
+    const int64_t n2 = pfa_fasta_index(text, s.size(), recs.data(), (uint64_t)n);
+    if (n2 != n) { fprintf(stderr, "index count changed %lld -> %lld\n", (long long)n, (long long)n2); abort(); }
+    uint32_t maxlen = 0;
+    for (auto& r : recs) maxlen = r.seq_len > maxlen ? r.seq_len : maxlen;
+    const uint32_t stride = ((maxlen + 15u) & ~15u) + 16u * below(3);
+    if (stride) {
+      uint8_t* out = (uint8_t*)malloc((size_t)n * stride);
+      (void)pfa_fasta_pack(text, s.size(), recs.data(), (uint64_t)n, out, stride);
+      if (n > 1) (void)pfa_fasta_pack(text, s.size(), recs.data(), 1, out, stride);
+      free(out);
+    }
+    // a too-small stride and a too-small record table must be refused, not overrun
+    if (maxlen > 16) {
+      uint8_t* out = (uint8_t*)malloc((size_t)n * 16);
+      (void)pfa_fasta_pack(text, s.size(), recs.data(), (uint64_t)n, out, 16);
+      free(out);
+    }
+    if (n > 1) (void)pfa_fasta_index(text, s.size(), recs.data(), (uint64_t)n - 1);
+  }
+  free(text);
+}
+
+static void fuzz_files(const char* dir) {
+  const uint32_t nf = 1 + below(12);
+  std::vector<std::string> paths;
+  for (uint32_t i = 0; i < nf; ++i) {
+    std::string p = std::string(dir) + "/f" + std::to_string(i) + ".fa";
+    if (below(10) == 0) p += ".missing";
+    else {
+      FILE* f = fopen(p.c_str(), "wb");
+      std::string s;
+      if (below(3) == 0) s = random_fasta();
+      else {   // a well-formed alignment, sometimes ragged
+        const uint32_t rows = 1 + below(6), len = below(300);
+        for (uint32_t r = 0; r < rows; ++r) {
+          s += ">r" + std::to_string(r) + "\n";
+          s += std::string(len + (below(12) == 0 ? 1 : 0), "ACGT"[below(4)]) + "\n";
+        }
+      }
+      fwrite(s.data(), 1, s.size(), f);
+      fclose(f);
+    }
+    paths.push_back(p);
+  }
+  std::vector<const char*> cp;
+  for (auto& p : paths) cp.push_back(p.c_str());
+  const uint64_t cap = 256u * below(40);                       // often too small: files get deferred
+  uint8_t* bases = (uint8_t*)malloc(cap ? cap : 1);
+  std::vector<pfa_file_info> info(nf);
+  const uint64_t names_cap = below(3) ? 4096 : below(16);
+  char* names = (char*)malloc(names_cap ? names_cap : 1);
+  uint64_t used = 0, names_used = 0;
+  (void)pfa_fasta_load_files(cp.data(), nf, 16u << below(5), 1 + below(4), bases, cap, info.data(),
+                             below(2) ? names : nullptr, names_cap, &used, &names_used);
+  if (used > cap) { fprintf(stderr, "load_files used %llu > cap %llu\n", (unsigned long long)used, (unsigned long long)cap); abort(); }
+  free(names);
+  free(bases);
+  for (auto& p : paths) unlink(p.c_str());
+}
+
+static void fuzz_rows() {
+  const uint32_t n = below(50);
+  std::string blob;
+  std::vector<uint64_t> off(n + 1, 0);
+  std::vector<uint32_t> seg(n), nrows(n);
+  std::vector<uint64_t> h(n);
+  std::vector<double> seqlen(n), a1(n), e1(n), e2(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    blob += "f" + std::to_string(below(100000)) + "," + std::to_string(below(100000)) + ",NA," + std::to_string(below(300)) + ",";
+    off[i + 1] = blob.size();
+    seg[i] = below(4) ? below(100000) : 0;
+    nrows[i] = below(20) ? 2 + below(400) : below(3);
+    h[i] = rnd() >> below(64);
+    seqlen[i] = below(20) ? 1 + below(100000) : 0.0;
+    a1[i] = below(20) ? 0.5 + below(1000) / 100.0 : 0.0;
+    e1[i] = (int32_t(below(2001)) - 1000) / 5000.0;
+    e2[i] = (int32_t(below(2001)) - 1000) / 500000.0;
+  }
+  const uint64_t cap = below(4) ? blob.size() + 128ull * n + 16 : below(200);
+  char* out = (char*)malloc(cap ? cap : 1);
+  int64_t bad = -1;
+  const int64_t got = pfa_format_plain_rows(blob.data(), off.data(), n, seg.data(), h.data(), nrows.data(), seqlen.data(),
+                                            a1.data(), e1.data(), e2.data(), (int)below(2), out, cap, &bad);
+  if (got > (int64_t)cap) { fprintf(stderr, "format wrote %lld > cap %llu\n", (long long)got, (unsigned long long)cap); abort(); }
+  free(out);
+  char buf[32];
+  union { uint64_t u; double d; } x;
+  x.u = rnd();
+  const int len = pfa_format_double(x.d, buf);
+  if (len <= 0 || len > 32) { fprintf(stderr, "repr length %d\n", len); abort(); }
+}
+
+int main(int argc, char** argv) {
+  const long iters = argc > 1 ? atol(argv[1]) : 20000;
+  const char* dir = argc > 2 ? argv[2] : "/tmp";
+  for (long i = 0; i < iters; ++i) {
+    fuzz_text(random_fasta());
+    if (i % 16 == 0) fuzz_files(dir);
+    fuzz_rows();
+  }
+  printf("host fuzz: %ld iterations clean\n", iters);
+  return 0;
+}
