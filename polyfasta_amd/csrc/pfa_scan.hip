@@ -1442,11 +1442,7 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
     PLAN_HIP(hipMalloc((void**)&p->d_syn_bm, nt * lb * sizeof(uint64_t)));
     PLAN_HIP(hipMalloc((void**)&p->d_non_bm, nt * lb * sizeof(uint64_t)));
   }
-  for (int i = 0; i < pfa::kEventRing; ++i) {
-    PLAN_HIP(hipEventCreate(&p->ev0[i]));
-    PLAN_HIP(hipEventCreate(&p->ev1[i]));
-  }
-  PLAN_HIP(hipStreamSynchronize(st));
+  PLAN_HIP(hipStreamSynchronize(st));   // (the timing events of the ring are created on first use)
 #undef PLAN_HIP
   *out = p;
   return PFA_OK;
@@ -1483,6 +1479,8 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   a.pad = 0u;
 
   const int slot = (int)(p->n_runs % pfa::kEventRing);
+  if (!p->ev0[slot]) PFA_HIP(hipEventCreate(&p->ev0[slot]));
+  if (!p->ev1[slot]) PFA_HIP(hipEventCreate(&p->ev1[slot]));
   PFA_HIP(hipEventRecord(p->ev0[slot], st));
   int rc;
   // kernel STAGE: 2 = LDS-DMA non-temporal (default), 1 = register staging, 0 = LDS-DMA default cache policy
