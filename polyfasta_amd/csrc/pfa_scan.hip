@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   const uint32_t nbins = N / 2u;
   const bool mapped = !LEAN && D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
   if (mapped)
-    for (uint32_t i = lane; i < N; i += 64u) rowmap[i] = A.row_idx[D.row_idx_off + i];
+    // the row's byte offset in the matrix, in 16-byte units (plans keep matrices below 64 GB)
+    for (uint32_t i = lane; i < N; i += 64u) rowmap[i] = A.row_idx[D.row_idx_off + i] * (D.row_stride >> 4);
   for (uint32_t i = lane; i < nbins; i += 64u) hist[i] = 0u;
   if (cds)
   {
@@ -320,20 +321,22 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
         if (rr < N % G::RPI)
           __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
       } else {
-        for (uint32_t g = 0; g < n_inst; ++g) {
-          const uint32_t r = g * G::RPI + rr;
-          if (r < N) {
-            const uint8_t* src = mat + (uint64_t)rowmap[r] * D.row_stride + col;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
-          }
-        }
+        const uint8_t* const base = mat + col;
+        const uint32_t n_full = N / G::RPI;
+        uint32_t g = 0;
+        for (; g < n_full; ++g)
+          __builtin_amdgcn_global_load_lds((gptr_t)(base + ((uint64_t)rowmap[g * G::RPI + rr] << 4)),
+                                           (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
+        if (rr < N % G::RPI)
+          __builtin_amdgcn_global_load_lds((gptr_t)(base + ((uint64_t)rowmap[g * G::RPI + rr] << 4)),
+                                           (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
       }
     } else {
 #pragma unroll 4
       for (uint32_t g = 0; g < n_inst; ++g) {
         const uint32_t r = g * G::RPI + rr;
         if (r < N) {
-          const uint4 v = *reinterpret_cast<const uint4*>(mat + (uint64_t)(mapped ? rowmap[r] : r) * D.row_stride + col);
+          const uint4 v = *reinterpret_cast<const uint4*>(mat + (mapped ? (uint64_t)rowmap[r] << 4 : (uint64_t)r * D.row_stride) + col);
           *reinterpret_cast<uint4*>(tile8 + g * 1024u + lane * 16u) = v;
         }
       }
@@ -762,7 +765,8 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   for (uint32_t i = lane; i < HB; i += 64u) hist[i] = 0u;
   // lane r holds the matrix row of the chunk's row r; the next chunk's are fetched while this one is scanned
   uint32_t idx_cur = 0u;
-  if (mapped && lane < umin(R, N)) idx_cur = ridx[lane];
+  const uint32_t stride16 = D.row_stride >> 4;
+  if (mapped && lane < umin(R, N)) idx_cur = ridx[lane] * stride16;
   __syncthreads();
 
   uint32_t acc_S = 0u, acc_bad = 0u;
@@ -787,9 +791,10 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     const uint32_t n_inst = (Rc + 3u) / 4u;
     for (uint32_t g = 0; g < n_inst; ++g) {
       const uint32_t r = 4u * g + rr;
-      const uint32_t row = mapped ? (uint32_t)__shfl((int)idx_rows, (int)(r & 63u)) : r0 + r;
+      // mapped: the lanes hold byte offsets of the chunk's rows in 16-byte units
+      const uint32_t held = mapped ? (uint32_t)__shfl((int)idx_rows, (int)(r & 63u)) : 0u;
       if (r < Rc) {
-        const uint8_t* src = mat + (uint64_t)row * D.row_stride + col;
+        const uint8_t* src = mat + (mapped ? (uint64_t)held << 4 : (uint64_t)(r0 + r) * D.row_stride) + col;
         if constexpr (STAGE == 1)
           *reinterpret_cast<uint4*>(tile8 + g * 1024u + lane * 16u) = *reinterpret_cast<const uint4*>(src);
         else
@@ -813,7 +818,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       uint32_t idx_nxt = idx_cur;
       if (mapped && multi) {
         const uint32_t r0n = r0 + R < N ? r0 + R : 0u;
-        if (lane < umin(R, N - r0n)) idx_nxt = ridx[r0n + lane];
+        if (lane < umin(R, N - r0n)) idx_nxt = ridx[r0n + lane] * stride16;
       }
       if constexpr (STAGE != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -1334,6 +1339,10 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
     } else {
       if (!row_idx || (uint64_t)d.row_idx_off + d.n_rows > n_row_idx) {
         pfa::set_error("desc %u: row_idx range out of bounds", i);
+        return PFA_ERR_ARG;
+      }
+      if ((uint64_t)d.mat_rows * d.row_stride > (1ull << 36)) {
+        pfa::set_error("desc %u: a matrix scanned through a row-index list must be smaller than 64 GB", i);
         return PFA_ERR_ARG;
       }
       for (uint32_t r = 0; r < d.n_rows; ++r)
