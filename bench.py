@@ -213,7 +213,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "pfa::scan_tall_kernel" if plan.rows_per_chunk else "pfa::scan_kernel", "kernel_ms_avg": k_avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "frac_of_measured_copy_6290": achieved / 6290.0},
+                         "frac_of_measured_copy_6290": achieved / 6290.0,
+                         # best plain streaming read measured on this pool (tools/ubench/read_stream.hip)
+                         "frac_of_measured_read_6860": achieved / 6860.0},
             "timing_ms": {"enqueue": t_enq * 1e3, "until_kernels_done": t_run * 1e3, "fetch": t_fetch * 1e3,
                           "kernel_ms_min": float(kms.min()), "kernel_ms_max": float(kms.max())},
             "check": {"mean_seg_sites": float(res["seg_sites"].mean()),
