@@ -182,12 +182,6 @@ __device__ inline unsigned long long wave_or_uniform(unsigned long long v) {
 __device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ inline uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
-// codon of three bytes: index, or -1 when any byte is not exactly A/C/G/T (PolyFastA.py:301)
-__device__ inline int codon_of(uint32_t x0, uint32_t x1, uint32_t x2) {
-  const bool ok = base_clean(x0) && base_clean(x1) && base_clean(x2);
-  return ok ? int(base_code(x0) * 16u + base_code(x1) * 4u + base_code(x2)) : -1;
-}
-
 // Wave-uniform form of classify_sense_mask (pfa_codon.h; PolyFastA.py:331-434) for a set `ms`
 // held in scalar registers: lane c stands for codon c (`my_info` = annot_info[c], `my_same` =
 // same_annot[c]), so the multiplicity rule for three or more codons needs no loop — a codon's
@@ -229,6 +223,262 @@ __device__ inline uint32_t classify_uniform(unsigned long long ms, uint32_t lane
   return s | n << 3;
 }
 
+
+// ---------------------------------------------------------------- the coding pass
+// Everything the syn / nonsyn split does once the allele scan of a tile is complete
+// (PolyFastA.py:284-315, 319-434), shared by scan_kernel and scan_tall_kernel.  Tiles are 256
+// (64) sites wide and line-aligned; 256 = 1 (mod 3), so the first codon of tile t starts
+// t mod 3 sites before it: the tier-1 words of the previous tile's last lane are carried in
+// registers, and chunks of coding plans hold a multiple of 3 tiles, so a chunk always starts
+// on a codon boundary.  What a kernel supplies: the tile's tier-1 words, a reader of per-site
+// H | allele mask << 24 (variable sites only), and a reader of the codon set of one column.
+template <int LB, bool LEAN>
+struct CodonPass {
+  static constexpr uint32_t WW = 64u * LB, NIT = LB == 4 ? 2u : 1u;
+  // wave constants: lane c stands for codon c in the tables below
+  uint32_t lane;
+  uint32_t my_info;               // annot_info[c] (classify_uniform)
+  unsigned long long my_same;     // same_annot[c]
+  uint32_t my_cinfo;              // synonymous-neighbour count | stop << 7, read with ds_bpermute
+  uint32_t my_slut[3];            // the three 256-byte planes of SingleLut, one word per lane each
+  uint32_t* synhist;              // LDS: PFA_SYN_BINS bins of synonymous-site numerators by codon count
+  unsigned long long* syn_bm;     // optional per-site S / N bitmaps
+  unsigned long long* non_bm;
+  uint32_t tile_off;
+  // per-lane partial sums of the chunk
+  uint32_t acc_segS = 0u, acc_segN = 0u, acc_stops = 0u, acc_missing = 0u, acc_syn1 = 0u;
+  unsigned long long acc_HS = 0ull, acc_HN = 0ull;
+  uint32_t carry_va = 0u, carry_vd = 0u;   // tier-1 AND / XOR words of the previous tile's last lane
+  // per tile: the codon columns that END at one of this lane's sites
+  uint32_t xw[2], dw[2];          // 3 consensus bytes, 3 XOR bytes (0 = monomorphic) per candidate column
+  int endo[2];                    // tile-relative site where it ends, or -1
+  uint64_t mjoint[2];             // ballots: columns with two or three variable positions
+  bool single[2], mono[2];
+  uint32_t pv[2];                 // the variable position of a `single` column
+  uint32_t site0;
+
+  __device__ void init(uint32_t lane_, uint32_t* synhist_, const ScanArgs& A, const pfa_desc& D) {
+    lane = lane_;
+    synhist = synhist_;
+    syn_bm = A.syn_bm;
+    non_bm = A.non_bm;
+    tile_off = D.tile_off;
+    my_info = d_tables.annot_info[lane];
+    my_same = d_tables.same_annot[lane];
+    my_cinfo = (uint32_t)d_tables.syn3[lane] | (uint32_t)((d_tables.stop_mask >> lane) & 1ull) << 7;
+#pragma unroll
+    for (uint32_t pl = 0; pl < 3u; ++pl) my_slut[pl] = reinterpret_cast<const uint32_t*>(d_single_lut.v)[pl * 64u + lane];
+  }
+
+  // table entry of another lane (the LDS crossbar, no LDS memory); every lane must be enabled
+  __device__ static uint32_t lane_lookup(uint32_t from_lane, uint32_t mine) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)mine);
+  }
+
+  __device__ void mark_site(bool is_s, int rel_site) const {
+    const uint32_t site = site0 + (uint32_t)rel_site;   // rel_site may be -2..-1: previous tile
+    const uint64_t w = (uint64_t)(tile_off + site / WW) * LB + (site % WW) % LB;
+    atomicOr(&(is_s ? syn_bm : non_bm)[w], 1ull << ((site % WW) / LB));
+  }
+
+  // Register window: every lane looks at the codon columns that END at one of its own sites.
+  // The three bytes (tier-1 AND word = the consensus byte of a monomorphic site) and the three
+  // "varies" flags come from this lane's and the previous lane's tier-1 words (lane 0: the words
+  // carried over from the previous tile): no memory traffic for the 87 % of columns that do not vary.
+  __device__ void window(uint32_t va, uint32_t vd, uint32_t site0_, uint32_t lim) {
+    site0 = site0_;
+    if constexpr (LB == 4) {
+      uint32_t pa = wave_shr1(va), pd = wave_shr1(vd);
+      if (lane == 0u) { pa = carry_va; pd = carry_vd; }
+      carry_va = __builtin_amdgcn_readlane(va, 63);
+      carry_vd = __builtin_amdgcn_readlane(vd, 63);
+      const unsigned long long Wa = (unsigned long long)pa | (unsigned long long)va << 32;
+      const unsigned long long Wd = (unsigned long long)pd | (unsigned long long)vd << 32;
+      const uint32_t o1 = (5u - (site0 + 4u * lane) % 3u) % 3u;   // first own site that ends a codon
+#pragma unroll
+      for (uint32_t it = 0; it < 2u; ++it) {
+        const uint32_t o = o1 + 3u * it;
+        const bool has = o < 4u && 4u * lane + o < lim;
+        xw[it] = (uint32_t)(Wa >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
+        dw[it] = (uint32_t)(Wd >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
+        endo[it] = has ? (int)(4u * lane + o) : -1;
+      }
+    } else {
+      uint32_t a1 = __shfl_up(va, 1), a2 = __shfl_up(va, 2), d1 = __shfl_up(vd, 1), d2 = __shfl_up(vd, 2);
+      if (lane == 0u) { a1 = carry_va >> 8; d1 = carry_vd >> 8; a2 = carry_va & 0xFFu; d2 = carry_vd & 0xFFu; }
+      if (lane == 1u) { a2 = carry_va >> 8; d2 = carry_vd >> 8; }
+      const uint32_t la = __shfl(va, 62) | __shfl(va, 63) << 8, ld = __shfl(vd, 62) | __shfl(vd, 63) << 8;
+      carry_va = la;
+      carry_vd = ld;
+      xw[0] = (a2 & 0xFFu) | (a1 & 0xFFu) << 8 | (va & 0xFFu) << 16;
+      dw[0] = (d2 & 0xFFu) | (d1 & 0xFFu) << 8 | (vd & 0xFFu) << 16;
+      endo[0] = ((site0 + lane) % 3u == 2u && lane < lim) ? (int)lane : -1;
+      xw[1] = dw[1] = 0u;
+      endo[1] = -1;
+    }
+    mjoint[0] = mjoint[1] = 0ull;
+    single[0] = single[1] = mono[0] = mono[1] = false;
+    pv[0] = pv[1] = 0u;
+#pragma unroll
+    for (uint32_t it = 0; it < NIT; ++it) {
+      bool joint = false;
+      if (endo[it] >= 0) {
+        const uint32_t dv = dw[it];
+        const bool v0 = (dv & 0xFFu) != 0u, v1 = (dv & 0xFF00u) != 0u, v2 = (dv & 0xFF0000u) != 0u;
+        const uint32_t nvar = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
+        joint = nvar >= 2u;                                // rare: the codons must be read row by row
+        single[it] = nvar == 1u;                           // one variable position: resolved from its allele mask
+        mono[it] = nvar == 0u;
+        pv[it] = v0 ? 0u : v1 ? 1u : 2u;
+      }
+      mjoint[it] = __ballot(joint);
+    }
+  }
+
+  // Columns with two or three variable positions (~0.6 %), one at a time: `read_set(rel)` returns
+  // this lane's share of the column's codon-presence set (the kernel reads one row per lane);
+  // the sets are OR-reduced with DPP moves and the classifier runs on the wave-uniform set
+  // (PolyFastA.py:301-315,319-434).  `hget(rel)`: H | allele mask << 24 of a variable site.
+  template <class ReadSet, class HGet>
+  __device__ void joint_columns(ReadSet read_set, HGet hget) {
+#pragma unroll
+    for (uint32_t it = 0; it < NIT; ++it) {
+      for (uint64_t m = mjoint[it]; m != 0ull; m &= m - 1ull) {
+        const uint32_t owner = (uint32_t)__builtin_ctzll(m);
+        const int rel = __builtin_amdgcn_readlane(endo[it], owner) - 2;
+        const unsigned long long M = wave_or_uniform(read_set(rel));
+        const uint32_t k = (uint32_t)__popcll(M);
+        if (k == 0u) { acc_missing += lane == 0u ? 1u : 0u; continue; }
+        constexpr unsigned long long kStop = kHostTables.stop_mask;
+        const uint32_t t3 = (uint32_t)__popcll(M & kHostTables.t_mask[1]) + 2u * (uint32_t)__popcll(M & kHostTables.t_mask[2]) +
+                            3u * (uint32_t)__popcll(M & kHostTables.t_mask[3]) + 4u * (uint32_t)__popcll(M & kHostTables.t_mask[4]);
+        const bool stop = (M & kStop) != 0ull;
+        const uint32_t labels = classify_uniform(M & ~kStop, lane, my_info, my_same);
+        if (lane == 0u) {
+          if (k == 1u) acc_syn1 += t3;
+          else atomicAdd(&synhist[k], t3);
+          acc_stops += stop ? 1u : 0u;
+#pragma unroll
+          for (uint32_t p = 0; p < 3u; ++p) {
+            const bool is_s = (labels >> p) & 1u, is_n = (labels >> (3u + p)) & 1u;
+            if (is_s || is_n) {
+              const uint32_t hs = hget(rel + (int)p) & 0xFFFFFFu;
+              if (is_s) { acc_segS += 1u; acc_HS += hs; }
+              else { acc_segN += 1u; acc_HN += hs; }
+              if (!LEAN && syn_bm != nullptr) mark_site(is_s, rel + (int)p);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // Monomorphic columns and columns with ONE variable position: registers and tables only, so a
+  // kernel calls this after it has requested its next tile.
+  template <class HGet>
+  __device__ void mono_and_single_columns(HGet hget) {
+    // monomorphic: exactly-A/C/G/T test of the three consensus bytes at once (the canonical byte
+    // of the 2-bit code (x >> 1) & 3 is 0x41 + 2 code + 0x0F [code == 2]; a byte is clean iff it
+    // equals it), then one table read: synonymous weight | stop << 7.  Every lane computes and
+    // looks up, so that the ds_bpermute runs with all lanes enabled (a disabled lane would not
+    // supply its table entry).
+#pragma unroll
+    for (uint32_t it = 0; it < NIT; ++it) {
+      const uint32_t w = xw[it];
+      const uint32_t t2 = w & 0x060606u;
+      const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
+      const uint32_t bad = (0x414141u + t2 + (e2 << 4) - e2) ^ w;
+      const uint32_t tt = t2 >> 1;
+      const uint32_t ci = lane_lookup(((tt & 3u) << 4) | ((tt >> 6) & 0xCu) | ((tt >> 16) & 3u), my_cinfo);
+      if (mono[it]) {
+        if (bad == 0u) {
+          acc_syn1 += ci & 7u;
+          acc_stops += ci >> 7;
+        } else {
+          acc_missing += 1u;
+        }
+      }
+    }
+    // One variable position, on the lane that owns the column: the codon set is the consensus
+    // codon with every A/C/G/T allele of that position substituted (rows with another symbol
+    // there hold an unclean codon and drop out, PolyFastA.py:301).  Only that position can be
+    // labelled.  The two fixed bytes are the lane's consensus bytes; the allele mask and H of
+    // the variable site come from the allele scan.  All lanes run it, `valid` marks the lanes
+    // that own such a column (the table reads are ds_bpermute's and need every lane enabled).
+    auto single_col = [&](bool valid, uint32_t w, uint32_t p, int end_rel) {
+      const int rel = valid ? end_rel - 2 : 0;
+      const uint32_t hv = hget(rel + (int)p);
+      const uint32_t am = valid ? hv >> 24 : 0u;
+      // exactly-A/C/G/T test of the two fixed bytes (as above; the byte of position p is meaningless)
+      const uint32_t t2 = w & 0x060606u;
+      const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
+      const uint32_t bad = ((0x414141u + t2 + (e2 << 4) - e2) ^ w) & ~(0xFFu << (8u * p));
+      const uint32_t k = bad ? 0u : (uint32_t)__popc(am);   // distinct clean codons
+      const uint32_t tt = t2 >> 1;
+      const uint32_t c0 = tt & 3u, c1 = (tt >> 8) & 3u, c2 = (tt >> 16) & 3u;
+      const uint32_t b4 = p == 0u ? (c1 << 2 | c2) : p == 1u ? (c0 << 2 | c2) : (c0 << 2 | c1);
+      const uint32_t j = b4 * 16u + (am & 15u);             // entry of plane p
+      const uint32_t w0 = lane_lookup(j >> 2, my_slut[0]), w1 = lane_lookup(j >> 2, my_slut[1]), w2 = lane_lookup(j >> 2, my_slut[2]);
+      const uint32_t v = ((p == 0u ? w0 : p == 1u ? w1 : w2) >> (8u * (j & 3u))) & 0xFFu;
+      if (!valid) return;
+      if (k == 0u) { acc_missing += 1u; return; }
+      const uint32_t t3 = v & 0x1Fu;
+      if (k == 1u) acc_syn1 += t3;
+      else atomicAdd(&synhist[k], t3);
+      acc_stops += (v >> 5) & 1u;
+      const bool is_s = (v & 0x40u) != 0u, is_n = (v & 0x80u) != 0u;
+      const uint32_t hs = hv & 0xFFFFFFu;
+      if (is_s) { acc_segS += 1u; acc_HS += hs; }
+      if (is_n) { acc_segN += 1u; acc_HN += hs; }
+      if (!LEAN && (is_s || is_n) && syn_bm != nullptr) mark_site(is_s, rel + (int)p);
+    };
+    const bool any1 = single[0] || single[1];
+    if (__any(any1)) {
+      const uint32_t sel = single[0] ? 0u : 1u;
+      single_col(any1, sel ? xw[1] : xw[0], (sel ? pv[1] : pv[0]) % 3u, sel ? endo[1] : endo[0]);
+    }
+    const bool both = single[0] && single[1];            // a lane owning two such columns: rare
+    if (__any(both)) single_col(both, xw[1], pv[1] % 3u, endo[1]);
+  }
+
+  // the trailing 1-2 sites of an alignment whose length is not a multiple of 3 never form a
+  // clean codon (PolyFastA.py:301-305)
+  __device__ void last_tile(uint32_t L) {
+    if ((L % 3u) != 0u && lane == 0u) acc_missing += 1u;
+  }
+
+  __device__ void flush(pfa_result* R, uint32_t* syn_num_unit) {
+    acc_segS = wave_sum(acc_segS);
+    acc_segN = wave_sum(acc_segN);
+    acc_stops = wave_sum(acc_stops);
+    acc_missing = wave_sum(acc_missing);
+    acc_syn1 = wave_sum(acc_syn1);
+    acc_HS = wave_sum(acc_HS);
+    acc_HN = wave_sum(acc_HN);
+    if (lane == 0u) {
+      if (acc_segS) atomicAdd(&R->seg_S, acc_segS);
+      if (acc_segN) atomicAdd(&R->seg_N, acc_segN);
+      if (acc_stops) atomicAdd(&R->nstops, acc_stops);
+      if (acc_missing) atomicAdd(&R->missing_cols, acc_missing);
+      if (acc_HS) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H_S), acc_HS);
+      if (acc_HN) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H_N), acc_HN);
+      if (acc_syn1) atomicAdd(&syn_num_unit[1], acc_syn1);
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) {
+      const uint32_t v = synhist[i];
+      if (v) atomicAdd(&syn_num_unit[i], v);
+    }
+  }
+};
+
+// codon of three bytes packed in a word (byte 0 = first base): its index as a one-hot 64-bit set,
+// or 0 when any byte is not exactly A/C/G/T (PolyFastA.py:301)
+__device__ inline unsigned long long codon_bit(uint32_t x0, uint32_t x1, uint32_t x2) {
+  const bool ok = base_clean(x0) && base_clean(x1) && base_clean(x2);
+  return ok ? 1ull << (base_code(x0) * 16u + base_code(x1) * 4u + base_code(x2)) : 0ull;
+}
+
 // ---------------------------------------------------------------- the kernel
 // LEAN: the plan has no row-index list and wants no per-site bitmap (the batch path of the CLI
 // and the bench): those branches, and the scalar registers they pin, are compiled out.
@@ -264,21 +514,6 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   uint8_t* const carry = lds + lo.carry;
   uint32_t* const synhist = reinterpret_cast<uint32_t*>(lds + lo.synhist);
 
-  // lane c stands for codon c in the wave-uniform classifier
-  const uint32_t my_info = HAS_CDS ? d_tables.annot_info[lane] : 0u;
-  const unsigned long long my_same = HAS_CDS ? d_tables.same_annot[lane] : 0ull;
-  // small tables live in registers, one entry per lane, and are read with ds_bpermute (the LDS
-  // crossbar, no LDS memory): per codon the synonymous-neighbour count | stop << 7, and the three
-  // 256-byte planes of the single-position table (pfa_codon.h: SingleLut), one word per lane each
-  const uint32_t my_cinfo = HAS_CDS ? (uint32_t)d_tables.syn3[lane] | (uint32_t)((d_tables.stop_mask >> lane) & 1ull) << 7 : 0u;
-  uint32_t my_slut[3] = {0u, 0u, 0u};
-  if constexpr (HAS_CDS) {
-#pragma unroll
-    for (uint32_t pl = 0; pl < 3u; ++pl) my_slut[pl] = reinterpret_cast<const uint32_t*>(d_single_lut.v)[pl * 64u + lane];
-  }
-  auto lane_lookup = [&](uint32_t from_lane, uint32_t mine) -> uint32_t {
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)mine);
-  };
   const uint32_t nbins = N / 2u;
   const bool mapped = !LEAN && D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
   if (mapped)
@@ -293,10 +528,9 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
 
   // per-lane partial sums of this chunk
   uint32_t acc_S = 0u, acc_bad = 0u;
-  uint32_t carry_va = 0u, carry_vd = 0u;   // tier-1 AND / XOR words of the previous tile's last lane
   unsigned long long acc_H = 0ull;
-  uint32_t acc_segS = 0u, acc_segN = 0u, acc_stops = 0u, acc_missing = 0u, acc_syn1 = 0u;
-  unsigned long long acc_HS = 0ull, acc_HN = 0ull;
+  CodonPass<LB, LEAN> cp;
+  if constexpr (HAS_CDS) cp.init(lane, synhist, A, D);
 
   const uint8_t* const mat = A.bases + D.base_off;
   const uint32_t n_inst = (N + G::RPI - 1u) / G::RPI;
@@ -469,121 +703,23 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       }
     }
 
-    // ---------------- coding sequences: the codon columns that END in this tile
-    // Tiles stay 256 (64) sites wide and line-aligned; 256 = 1 (mod 3), so the first codon of
-    // tile t starts t mod 3 sites before it.  Those sites (bytes of every row + their H) are
-    // carried over in LDS from the previous tile of this wave's chunk; chunks of coding plans
-    // hold a multiple of 3 tiles, so a chunk always starts on a codon boundary.
+    // ---------------- coding sequences: the codon columns that END in this tile (CodonPass)
     if (cds) {
       __syncthreads();   // tier 2's hsite entries are visible
+      cp.window(va, vd, site0, lim);
+      // columns with two or three variable positions: one row per lane out of the LDS tile; the
+      // one or two sites a codon reaches back into the previous tile come from `carry`
       auto cell = [&](uint32_t r, int rel) -> uint32_t {
         const uint8_t* q = rel < 0 ? carry + 2u * r + (uint32_t)(2 + rel) : tile8 + r * G::WW + (uint32_t)rel;
         return *q;
       };
-      // optional per-site S / N bitmaps
-      auto mark_site = [&](bool is_s, int rel_site) {
-        const uint32_t site = site0 + (uint32_t)rel_site;   // rel_site may be -2..-1: previous tile
-        const uint64_t w = (uint64_t)(D.tile_off + site / G::WW) * LB + (site % G::WW) % LB;
-        atomicOr(&(is_s ? A.syn_bm : A.non_bm)[w], 1ull << ((site % G::WW) / LB));
-      };
-
-      // Register window: every lane looks at the codon columns that END at one of its own
-      // sites.  The three bytes (tier-1 AND word = the consensus byte of a monomorphic site)
-      // and the three "varies" flags come from this lane's and the previous lane's tier-1
-      // words (lane 0: the words carried over from the previous tile), with no LDS traffic
-      // for the 87 % of columns that do not vary.
-      uint32_t xw[2], dw[2];     // per candidate column: 3 consensus bytes, 3 XOR bytes (0 = monomorphic)
-      int endo[2];               // tile-relative site where it ends, or -1
-      if constexpr (LB == 4) {
-        uint32_t pa = wave_shr1(va), pd = wave_shr1(vd);
-        if (lane == 0u) { pa = carry_va; pd = carry_vd; }
-        carry_va = __builtin_amdgcn_readlane(va, 63);
-        carry_vd = __builtin_amdgcn_readlane(vd, 63);
-        const unsigned long long Wa = (unsigned long long)pa | (unsigned long long)va << 32;
-        const unsigned long long Wd = (unsigned long long)pd | (unsigned long long)vd << 32;
-        const uint32_t o1 = (5u - (site0 + 4u * lane) % 3u) % 3u;   // first own site that ends a codon
-#pragma unroll
-        for (uint32_t it = 0; it < 2u; ++it) {
-          const uint32_t o = o1 + 3u * it;
-          const bool has = o < 4u && 4u * lane + o < lim;
-          xw[it] = (uint32_t)(Wa >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
-          dw[it] = (uint32_t)(Wd >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
-          endo[it] = has ? (int)(4u * lane + o) : -1;
-        }
-      } else {
-        uint32_t a1 = __shfl_up(va, 1), a2 = __shfl_up(va, 2), d1 = __shfl_up(vd, 1), d2 = __shfl_up(vd, 2);
-        if (lane == 0u) { a1 = carry_va >> 8; d1 = carry_vd >> 8; a2 = carry_va & 0xFFu; d2 = carry_vd & 0xFFu; }
-        if (lane == 1u) { a2 = carry_va >> 8; d2 = carry_vd >> 8; }
-        const uint32_t la = __shfl(va, 62) | __shfl(va, 63) << 8, ld = __shfl(vd, 62) | __shfl(vd, 63) << 8;
-        carry_va = la;
-        carry_vd = ld;
-        xw[0] = (a2 & 0xFFu) | (a1 & 0xFFu) << 8 | (va & 0xFFu) << 16;
-        dw[0] = (d2 & 0xFFu) | (d1 & 0xFFu) << 8 | (vd & 0xFFu) << 16;
-        endo[0] = ((site0 + lane) % 3u == 2u && lane < lim) ? (int)lane : -1;
-        xw[1] = dw[1] = 0u;
-        endo[1] = -1;
-      }
-
-      constexpr uint32_t NIT = LB == 4 ? 2u : 1u;
-      uint64_t mjoint[2] = {0ull, 0ull};
-      bool single[2] = {false, false}, mono[2] = {false, false};
-      uint32_t pv[2] = {0u, 0u};
-#pragma unroll
-      for (uint32_t it = 0; it < NIT; ++it) {
-        bool joint = false;
-        if (endo[it] >= 0) {
-          const uint32_t dv = dw[it];
-          const bool v0 = (dv & 0xFFu) != 0u, v1 = (dv & 0xFF00u) != 0u, v2 = (dv & 0xFF0000u) != 0u;
-          const uint32_t nvar = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
-          joint = nvar >= 2u;                                // rare: the codons must be read row by row
-          single[it] = nvar == 1u;                           // one variable position: resolved from its allele mask
-          mono[it] = nvar == 0u;
-          pv[it] = v0 ? 0u : v1 ? 1u : 2u;
-        }
-        mjoint[it] = __ballot(joint);
-      }
-
-      // Columns with two or three variable positions (~0.6 %): one at a time, the whole wave
-      // reads the codon of one row per lane, the 64-bit codon-presence sets are OR-reduced with
-      // DPP moves (no LDS), and the classifier runs on the wave-uniform set
-      // (PolyFastA.py:301-315,319-434).
-      {
-#pragma unroll
-        for (uint32_t it = 0; it < NIT; ++it) {
-          for (uint64_t m = mjoint[it]; m != 0ull; m &= m - 1ull) {
-            const uint32_t owner = (uint32_t)__builtin_ctzll(m);
-            const int rel = __builtin_amdgcn_readlane(endo[it], owner) - 2;
+      cp.joint_columns(
+          [&](int rel) {
             unsigned long long Mv = 0ull;
-            for (uint32_t r = lane; r < N; r += 64u) {
-              const int code = codon_of(cell(r, rel), cell(r, rel + 1), cell(r, rel + 2));
-              if (code >= 0) Mv |= 1ull << code;
-            }
-            const unsigned long long M = wave_or_uniform(Mv);
-            const uint32_t k = (uint32_t)__popcll(M);
-            if (k == 0u) { acc_missing += lane == 0u ? 1u : 0u; continue; }
-            constexpr unsigned long long kStop = kHostTables.stop_mask;
-            const uint32_t t3 = (uint32_t)__popcll(M & kHostTables.t_mask[1]) + 2u * (uint32_t)__popcll(M & kHostTables.t_mask[2]) +
-                                3u * (uint32_t)__popcll(M & kHostTables.t_mask[3]) + 4u * (uint32_t)__popcll(M & kHostTables.t_mask[4]);
-            const bool stop = (M & kStop) != 0ull;
-            const uint32_t labels = classify_uniform(M & ~kStop, lane, my_info, my_same);
-            if (lane == 0u) {
-              if (k == 1u) acc_syn1 += t3;
-              else atomicAdd(&synhist[k], t3);
-              acc_stops += stop ? 1u : 0u;
-#pragma unroll
-              for (uint32_t p = 0; p < 3u; ++p) {
-                const bool is_s = (labels >> p) & 1u, is_n = (labels >> (3u + p)) & 1u;
-                if (is_s || is_n) {
-                  const uint32_t hs = hsite_get(rel + (int)p) & 0xFFFFFFu;
-                  if (is_s) { acc_segS += 1u; acc_HS += hs; }
-                  else { acc_segN += 1u; acc_HN += hs; }
-                  if (!LEAN && A.syn_bm != nullptr) mark_site(is_s, rel + (int)p);
-                }
-              }
-            }
-          }
-        }
-      }
+            for (uint32_t r = lane; r < N; r += 64u) Mv |= codon_bit(cell(r, rel), cell(r, rel + 1), cell(r, rel + 2));
+            return Mv;
+          },
+          hsite_get);
       // carry the last two columns (bytes of every row) into the next tile
       for (uint32_t i = lane; i < N; i += 64u) {
         carry[2u * i] = tile8[i * G::WW + G::WW - 2u];
@@ -592,77 +728,8 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       // ---- nothing below reads the tile buffer: request the next tile now
       __syncthreads();
       if (tile + 1u < t1) stage(tile + 1u);
-
-      // monomorphic columns: exactly-A/C/G/T test of the three consensus bytes at once (the
-      // canonical byte of the 2-bit code (x >> 1) & 3 is 0x41 + 2 code + 0x0F [code == 2]; a byte
-      // is clean iff it equals it), then one LUT read: synonymous weight | stop << 7
-#pragma unroll
-      for (uint32_t it = 0; it < NIT; ++it) {
-        // (every lane computes and looks up, so that the ds_bpermute runs with all lanes enabled:
-        // a disabled lane would not supply its table entry)
-        const uint32_t w = xw[it];
-        const uint32_t t2 = w & 0x060606u;
-        const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
-        const uint32_t bad = (0x414141u + t2 + (e2 << 4) - e2) ^ w;
-        const uint32_t tt = t2 >> 1;
-        const uint32_t ci = lane_lookup(((tt & 3u) << 4) | ((tt >> 6) & 0xCu) | ((tt >> 16) & 3u), my_cinfo);
-        if (mono[it]) {
-          if (bad == 0u) {
-            acc_syn1 += ci & 7u;
-            acc_stops += ci >> 7;
-          } else {
-            acc_missing += 1u;
-          }
-        }
-      }
-
-      // Columns with ONE variable position, on the lane that owns the column: the codon set is
-      // the consensus codon with every A/C/G/T allele of that position substituted (rows with
-      // another symbol there hold an unclean codon and drop out, PolyFastA.py:301).  Only that
-      // position can be labelled.  The two fixed bytes are the lane's consensus bytes; the
-      // allele mask and H of the variable site come from tier 2 (hsite).
-      // (All lanes run it, `valid` marks the lanes that own such a column: the table reads are
-      // ds_bpermute's and need every lane enabled.)
-      auto single_col = [&](bool valid, uint32_t w, uint32_t p, int end_rel) {
-        const int rel = valid ? end_rel - 2 : 0;
-        const uint32_t hv = hsite_get(rel + (int)p);
-        const uint32_t am = valid ? hv >> 24 : 0u;
-        // exactly-A/C/G/T test of the two fixed bytes (as above; the byte of position p is meaningless)
-        const uint32_t t2 = w & 0x060606u;
-        const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
-        const uint32_t bad = ((0x414141u + t2 + (e2 << 4) - e2) ^ w) & ~(0xFFu << (8u * p));
-        const uint32_t k = bad ? 0u : (uint32_t)__popc(am);   // distinct clean codons
-        const uint32_t tt = t2 >> 1;
-        const uint32_t c0 = tt & 3u, c1 = (tt >> 8) & 3u, c2 = (tt >> 16) & 3u;
-        const uint32_t b4 = p == 0u ? (c1 << 2 | c2) : p == 1u ? (c0 << 2 | c2) : (c0 << 2 | c1);
-        const uint32_t j = b4 * 16u + (am & 15u);             // entry of plane p
-        const uint32_t w0 = lane_lookup(j >> 2, my_slut[0]), w1 = lane_lookup(j >> 2, my_slut[1]), w2 = lane_lookup(j >> 2, my_slut[2]);
-        const uint32_t v = ((p == 0u ? w0 : p == 1u ? w1 : w2) >> (8u * (j & 3u))) & 0xFFu;
-        if (!valid) return;
-        if (k == 0u) { acc_missing += 1u; return; }
-        const uint32_t t3 = v & 0x1Fu;
-        if (k == 1u) acc_syn1 += t3;
-        else atomicAdd(&synhist[k], t3);
-        acc_stops += (v >> 5) & 1u;
-        const bool is_s = (v & 0x40u) != 0u, is_n = (v & 0x80u) != 0u;
-        const uint32_t hs = hv & 0xFFFFFFu;
-        if (is_s) { acc_segS += 1u; acc_HS += hs; }
-        if (is_n) { acc_segN += 1u; acc_HN += hs; }
-        if (!LEAN && (is_s || is_n) && A.syn_bm != nullptr) mark_site(is_s, rel + (int)p);
-      };
-      {
-        const bool any1 = single[0] || single[1];
-        if (__any(any1)) {
-          const uint32_t sel = single[0] ? 0u : 1u;
-          single_col(any1, sel ? xw[1] : xw[0], (sel ? pv[1] : pv[0]) % 3u, sel ? endo[1] : endo[0]);
-        }
-        const bool both = single[0] && single[1];            // a lane owning two such columns: rare
-        if (__any(both)) single_col(both, xw[1], pv[1] % 3u, endo[1]);
-      }
-      // the trailing 1-2 sites of an alignment whose length is not a multiple of 3 never form
-      // a clean codon (PolyFastA.py:301-305)
-      if (tile + 1u == n_tiles && (L % 3u) != 0u && lane == 0u) acc_missing += 1u;
-
+      cp.mono_and_single_columns(hsite_get);
+      if (tile + 1u == n_tiles) cp.last_tile(L);
       // H of the last two sites, for the codons that straddle into the next tile
       if (lane < 2u) {
         if (h16) hsite16[(int)lane - 2] = hsite16[G::WW - 2u + lane];
@@ -679,40 +746,17 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   acc_S = wave_sum(acc_S);
   acc_bad = wave_sum(acc_bad);
   acc_H = wave_sum(acc_H);
-  if (cds) {
-    acc_segS = wave_sum(acc_segS);
-    acc_segN = wave_sum(acc_segN);
-    acc_stops = wave_sum(acc_stops);
-    acc_missing = wave_sum(acc_missing);
-    acc_syn1 = wave_sum(acc_syn1);
-    acc_HS = wave_sum(acc_HS);
-    acc_HN = wave_sum(acc_HN);
-  }
   if (lane == 0u) {
     if (acc_S) atomicAdd(&R->seg_sites, acc_S);
     if (acc_bad) atomicAdd(&R->sfs_bad, acc_bad);
     if (acc_H) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H), acc_H);
-    if (cds) {
-      if (acc_segS) atomicAdd(&R->seg_S, acc_segS);
-      if (acc_segN) atomicAdd(&R->seg_N, acc_segN);
-      if (acc_stops) atomicAdd(&R->nstops, acc_stops);
-      if (acc_missing) atomicAdd(&R->missing_cols, acc_missing);
-      if (acc_HS) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H_S), acc_HS);
-      if (acc_HN) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H_N), acc_HN);
-      if (acc_syn1) atomicAdd(&A.syn_num[(uint64_t)blockIdx.x * PFA_SYN_BINS + 1u], acc_syn1);
-    }
   }
   __syncthreads();
   for (uint32_t i = lane; i < nbins; i += 64u) {
     const uint32_t v = hist[i];
     if (v) atomicAdd(&A.sfs[D.sfs_off + i], v);
   }
-  if (cds) {
-    for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) {
-      const uint32_t v = synhist[i];
-      if (v) atomicAdd(&A.syn_num[(uint64_t)blockIdx.x * PFA_SYN_BINS + i], v);
-    }
-  }
+  if (cds) cp.flush(R, A.syn_num + (uint64_t)blockIdx.x * PFA_SYN_BINS);
 }
 
 
