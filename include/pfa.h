@@ -47,9 +47,9 @@ extern "C" {
 #define PFA_ERR_FORMAT (-7)     /* FASTA packer: not FASTA / unsupported byte */
 #define PFA_ERR_IO (-8)
 
-/* Rows per scan unit.  Non-coding units are streamed in row chunks, so the bound
- * is only what 32-bit counters hold; the rows of a coding unit (PFA_FLAG_CDS)
- * must fit one LDS column tile. */
+/* Rows per scan unit.  Units with many rows are streamed in row chunks, so the
+ * bound is what the counters hold: 32 bits for non-coding units, 24 bits for the
+ * per-site H of a coding unit (PFA_FLAG_CDS). */
 #define PFA_MAX_ROWS 1048576u
 #define PFA_MAX_ROWS_CDS 2048u
 
@@ -62,10 +62,9 @@ extern "C" {
 #define PFA_WANT_VAR_BITMAP 1u /* variable-site bitmap  -> `pos` of getvarsites        */
 #define PFA_WANT_SN_BITMAP 2u  /* S / N position bitmaps -> lists of getvarCDSsites    */
 
-/* Column-tile width (sites per wavefront tile): 256, except for plans with a
- * coding unit whose largest unit has more than 600 rows, where the tile narrows
- * to 64 sites so that N rows still fit LDS.  Query with pfa_tile_sites().
- * Bitmaps are laid out per tile. */
+/* Column-tile width (sites per wavefront tile): 256 for every plan (units with
+ * many rows stream their rows in chunks instead of narrowing the tile).  Query
+ * with pfa_tile_sites().  Bitmaps are laid out per tile. */
 #define PFA_TILE_SITES 256u
 
 /* One scan unit = one alignment, or one population's row subset of an
@@ -110,8 +109,8 @@ typedef struct pfa_result {
 typedef struct pfa_plan pfa_plan;
 
 /* tile geometry of a plan whose largest unit has `max_rows` rows and that holds
- * (`cds` = 1) or does not hold (0) a coding unit: sites per tile and 64-bit
- * words per tile of every bitmap.  tile_off of unit i = sum over earlier units
+ * (`cds` = 1) or does not hold (0) a coding unit: sites per tile (256) and 64-bit
+ * words per tile of every bitmap (4).  tile_off of unit i = sum over earlier units
  * of ceil(n_sites / pfa_tile_sites(max_rows, cds)). */
 uint32_t pfa_tile_sites(uint32_t max_rows, uint32_t cds);
 uint32_t pfa_var_words_per_tile(uint32_t max_rows, uint32_t cds);
@@ -172,7 +171,7 @@ int pfa_scan_batch(const uint8_t* bases, uint64_t n_bases_bytes,
 
 /* Bitmap layout ("tile-interleaved", the order the wavefront ballots produce),
  * the same for the variable-site, synonymous and non-synonymous bitmaps:
- * W = pfa_var_words_per_tile() words per tile (4, or 1 for narrow tiles); bit l
+ * W = pfa_var_words_per_tile() words per tile (4); bit l
  * of word b of tile t <-> site t*TILE + W*l + b.
  * pfa_bitmap_positions() expands one unit's words to ascending positions;
  * returns the count, or <0 if `cap` is too small. */

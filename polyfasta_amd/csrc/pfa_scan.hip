@@ -12,10 +12,10 @@
 // Kernel shape.  One 64-lane wavefront per workgroup; no
 // inter-wave synchronisation anywhere.  A wavefront owns a chunk of
 // consecutive column tiles of one unit.  Per tile (scan_kernel):
-//   stage   N rows x 64*LB sites -> LDS with LDS-DMA (global_load_lds_dwordx4,
+//   stage   N rows x 256 sites -> LDS with LDS-DMA (global_load_lds_dwordx4,
 //           one KiB per instruction, no VGPR round trip); each instruction
-//           covers 1024/(64*LB) rows so every lane moves 16 contiguous bytes
-//   tier 1  lane = LB adjacent sites; walk the rows with one conflict-free
+//           covers 4 rows so every lane moves 16 contiguous bytes
+//   tier 1  lane = 4 adjacent sites; walk the rows with one conflict-free
 //           ds_read per row, keep running AND / OR of the bytes: a site is
 //           monomorphic iff AND == OR (2 VALU ops per row per lane)
 //   compact ballot + mbcnt turn the per-lane flags into a dense list of the
@@ -28,8 +28,9 @@
 //           from a LUT, columns with one variable position from a compile-time
 //           table on the owning lane, columns with two or three (rare) read
 //           row by row, OR-reduced with DPP and classified wave-uniformly
-// Units of more than 64 rows without a coding flag run scan_tall_kernel, which
-// streams the rows of a tile in chunks (LDS per wave independent of N).
+// Plans whose units have too many rows to keep the CU full that way run
+// scan_tall_kernel, which streams the rows of a tile in chunks (LDS per wave
+// independent of N) and hands the same per-site results to the coding pass.
 // Per-chunk partial sums leave through integer atomics (order-independent).
 #include <algorithm>
 #include <cstdarg>
@@ -67,13 +68,13 @@ __constant__ pfa::SingleLut d_single_lut = pfa::make_single_lut();
 namespace pfa {
 
 // ---------------------------------------------------------------- geometry
-template <int LB>
-struct Geo {
+// Every kernel works on 256-site tiles: a lane owns LB = 4 adjacent sites (one 32-bit word of a
+// tile row), an LDS-DMA instruction moves 4 rows x 256 bytes.
+static constexpr int LB = 4;
+struct G {
   static constexpr uint32_t WW = 64u * LB;            // sites (= bytes) per LDS tile row
   static constexpr uint32_t LPR = WW / 16u;           // DMA lanes per row
   static constexpr uint32_t RPI = 64u / LPR;          // rows per DMA instruction
-  static constexpr uint32_t NCODMAX = (WW + 2u) / 3u;   // codon columns that can END inside one tile
-  static constexpr uint32_t CPASS = (NCODMAX + 63u) / 64u;
 };
 
 struct LdsLayout {
@@ -122,10 +123,10 @@ struct ScanArgs {
 };
 
 struct TallLayout {
-  uint32_t tile, list, cnt, hist, total;
+  uint32_t tile, list, cnt, hist, hsite, synhist, total;
 };
 
-PFA_HD inline TallLayout tall_layout(uint32_t rows_per_chunk, uint32_t max_slots, uint32_t hist_bins) {
+PFA_HD inline TallLayout tall_layout(uint32_t rows_per_chunk, uint32_t max_slots, uint32_t hist_bins, bool cds) {
   TallLayout o;
   o.tile = 0;                                   // R x 256 bytes
   o.list = round16(rows_per_chunk * 256u);      // list: per slot  x | d << 8 | mode << 16 | site << 24
@@ -134,7 +135,11 @@ PFA_HD inline TallLayout tall_layout(uint32_t rows_per_chunk, uint32_t max_slots
   // column path: its site list (256 B at `list`) and its 256-bin histogram (1 KiB behind it).
   const uint32_t slots_bytes = max_slots * 28u;
   o.hist = o.list + (slots_bytes > 1280u ? slots_bytes : 1280u);
-  o.total = o.hist + round16(hist_bins * 4u + 4u);
+  // coding plans: hsite[s] = H | allele mask << 24 of variable site s, with two entries in front for
+  // the last two sites of the previous tile, and the bins of synonymous-site numerators
+  o.hsite = o.hist + round16(hist_bins * 4u + 4u) + (cds ? 16u : 0u);
+  o.synhist = o.hsite + (cds ? 256u * 4u : 0u);
+  o.total = o.synhist + (cds ? round16(PFA_SYN_BINS * 4u) : 0u);
   return o;
 }
 
@@ -227,14 +232,14 @@ __device__ inline uint32_t classify_uniform(unsigned long long ms, uint32_t lane
 // ---------------------------------------------------------------- the coding pass
 // Everything the syn / nonsyn split does once the allele scan of a tile is complete
 // (PolyFastA.py:284-315, 319-434), shared by scan_kernel and scan_tall_kernel.  Tiles are 256
-// (64) sites wide and line-aligned; 256 = 1 (mod 3), so the first codon of tile t starts
+// sites wide and line-aligned; 256 = 1 (mod 3), so the first codon of tile t starts
 // t mod 3 sites before it: the tier-1 words of the previous tile's last lane are carried in
 // registers, and chunks of coding plans hold a multiple of 3 tiles, so a chunk always starts
 // on a codon boundary.  What a kernel supplies: the tile's tier-1 words, a reader of per-site
 // H | allele mask << 24 (variable sites only), and a reader of the codon set of one column.
-template <int LB, bool LEAN>
+template <bool LEAN>
 struct CodonPass {
-  static constexpr uint32_t WW = 64u * LB, NIT = LB == 4 ? 2u : 1u;
+  static constexpr uint32_t WW = 64u * LB, NIT = 2u;
   // wave constants: lane c stands for codon c in the tables below
   uint32_t lane;
   uint32_t my_info;               // annot_info[c] (classify_uniform)
@@ -287,34 +292,20 @@ struct CodonPass {
   // carried over from the previous tile): no memory traffic for the 87 % of columns that do not vary.
   __device__ void window(uint32_t va, uint32_t vd, uint32_t site0_, uint32_t lim) {
     site0 = site0_;
-    if constexpr (LB == 4) {
-      uint32_t pa = wave_shr1(va), pd = wave_shr1(vd);
-      if (lane == 0u) { pa = carry_va; pd = carry_vd; }
-      carry_va = __builtin_amdgcn_readlane(va, 63);
-      carry_vd = __builtin_amdgcn_readlane(vd, 63);
-      const unsigned long long Wa = (unsigned long long)pa | (unsigned long long)va << 32;
-      const unsigned long long Wd = (unsigned long long)pd | (unsigned long long)vd << 32;
-      const uint32_t o1 = (5u - (site0 + 4u * lane) % 3u) % 3u;   // first own site that ends a codon
+    uint32_t pa = wave_shr1(va), pd = wave_shr1(vd);
+    if (lane == 0u) { pa = carry_va; pd = carry_vd; }
+    carry_va = __builtin_amdgcn_readlane(va, 63);
+    carry_vd = __builtin_amdgcn_readlane(vd, 63);
+    const unsigned long long Wa = (unsigned long long)pa | (unsigned long long)va << 32;
+    const unsigned long long Wd = (unsigned long long)pd | (unsigned long long)vd << 32;
+    const uint32_t o1 = (5u - (site0 + 4u * lane) % 3u) % 3u;   // first own site that ends a codon
 #pragma unroll
-      for (uint32_t it = 0; it < 2u; ++it) {
-        const uint32_t o = o1 + 3u * it;
-        const bool has = o < 4u && 4u * lane + o < lim;
-        xw[it] = (uint32_t)(Wa >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
-        dw[it] = (uint32_t)(Wd >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
-        endo[it] = has ? (int)(4u * lane + o) : -1;
-      }
-    } else {
-      uint32_t a1 = __shfl_up(va, 1), a2 = __shfl_up(va, 2), d1 = __shfl_up(vd, 1), d2 = __shfl_up(vd, 2);
-      if (lane == 0u) { a1 = carry_va >> 8; d1 = carry_vd >> 8; a2 = carry_va & 0xFFu; d2 = carry_vd & 0xFFu; }
-      if (lane == 1u) { a2 = carry_va >> 8; d2 = carry_vd >> 8; }
-      const uint32_t la = __shfl(va, 62) | __shfl(va, 63) << 8, ld = __shfl(vd, 62) | __shfl(vd, 63) << 8;
-      carry_va = la;
-      carry_vd = ld;
-      xw[0] = (a2 & 0xFFu) | (a1 & 0xFFu) << 8 | (va & 0xFFu) << 16;
-      dw[0] = (d2 & 0xFFu) | (d1 & 0xFFu) << 8 | (vd & 0xFFu) << 16;
-      endo[0] = ((site0 + lane) % 3u == 2u && lane < lim) ? (int)lane : -1;
-      xw[1] = dw[1] = 0u;
-      endo[1] = -1;
+    for (uint32_t it = 0; it < 2u; ++it) {
+      const uint32_t o = o1 + 3u * it;
+      const bool has = o < 4u && 4u * lane + o < lim;
+      xw[it] = (uint32_t)(Wa >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
+      dw[it] = (uint32_t)(Wd >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
+      endo[it] = has ? (int)(4u * lane + o) : -1;
     }
     mjoint[0] = mjoint[1] = 0ull;
     single[0] = single[1] = mono[0] = mono[1] = false;
@@ -335,10 +326,38 @@ struct CodonPass {
     }
   }
 
-  // Columns with two or three variable positions (~0.6 %), one at a time: `read_set(rel)` returns
-  // this lane's share of the column's codon-presence set (the kernel reads one row per lane);
-  // the sets are OR-reduced with DPP moves and the classifier runs on the wave-uniform set
+  // One column with two or three variable positions, given the wave-uniform set `M` of its
+  // distinct clean codons: stop / synonymous-site bookkeeping and the classifier
   // (PolyFastA.py:301-315,319-434).  `hget(rel)`: H | allele mask << 24 of a variable site.
+  template <class HGet>
+  __device__ void joint_finish(unsigned long long M, int rel, HGet hget) {
+    const uint32_t k = (uint32_t)__popcll(M);
+    if (k == 0u) { acc_missing += lane == 0u ? 1u : 0u; return; }
+    constexpr unsigned long long kStop = kHostTables.stop_mask;
+    const uint32_t t3 = (uint32_t)__popcll(M & kHostTables.t_mask[1]) + 2u * (uint32_t)__popcll(M & kHostTables.t_mask[2]) +
+                        3u * (uint32_t)__popcll(M & kHostTables.t_mask[3]) + 4u * (uint32_t)__popcll(M & kHostTables.t_mask[4]);
+    const bool stop = (M & kStop) != 0ull;
+    const uint32_t labels = classify_uniform(M & ~kStop, lane, my_info, my_same);
+    if (lane == 0u) {
+      if (k == 1u) acc_syn1 += t3;
+      else atomicAdd(&synhist[k], t3);
+      acc_stops += stop ? 1u : 0u;
+#pragma unroll
+      for (uint32_t p = 0; p < 3u; ++p) {
+        const bool is_s = (labels >> p) & 1u, is_n = (labels >> (3u + p)) & 1u;
+        if (is_s || is_n) {
+          const uint32_t hs = hget(rel + (int)p) & 0xFFFFFFu;
+          if (is_s) { acc_segS += 1u; acc_HS += hs; }
+          else { acc_segN += 1u; acc_HN += hs; }
+          if (!LEAN && syn_bm != nullptr) mark_site(is_s, rel + (int)p);
+        }
+      }
+    }
+  }
+
+  // Columns with two or three variable positions (~0.6 %), one at a time (rows in LDS):
+  // `read_set(rel)` returns this lane's share of the column's codon-presence set (the kernel reads
+  // one row per lane); the sets are OR-reduced with DPP moves.
   template <class ReadSet, class HGet>
   __device__ void joint_columns(ReadSet read_set, HGet hget) {
 #pragma unroll
@@ -346,31 +365,35 @@ struct CodonPass {
       for (uint64_t m = mjoint[it]; m != 0ull; m &= m - 1ull) {
         const uint32_t owner = (uint32_t)__builtin_ctzll(m);
         const int rel = __builtin_amdgcn_readlane(endo[it], owner) - 2;
-        const unsigned long long M = wave_or_uniform(read_set(rel));
-        const uint32_t k = (uint32_t)__popcll(M);
-        if (k == 0u) { acc_missing += lane == 0u ? 1u : 0u; continue; }
-        constexpr unsigned long long kStop = kHostTables.stop_mask;
-        const uint32_t t3 = (uint32_t)__popcll(M & kHostTables.t_mask[1]) + 2u * (uint32_t)__popcll(M & kHostTables.t_mask[2]) +
-                            3u * (uint32_t)__popcll(M & kHostTables.t_mask[3]) + 4u * (uint32_t)__popcll(M & kHostTables.t_mask[4]);
-        const bool stop = (M & kStop) != 0ull;
-        const uint32_t labels = classify_uniform(M & ~kStop, lane, my_info, my_same);
-        if (lane == 0u) {
-          if (k == 1u) acc_syn1 += t3;
-          else atomicAdd(&synhist[k], t3);
-          acc_stops += stop ? 1u : 0u;
-#pragma unroll
-          for (uint32_t p = 0; p < 3u; ++p) {
-            const bool is_s = (labels >> p) & 1u, is_n = (labels >> (3u + p)) & 1u;
-            if (is_s || is_n) {
-              const uint32_t hs = hget(rel + (int)p) & 0xFFFFFFu;
-              if (is_s) { acc_segS += 1u; acc_HS += hs; }
-              else { acc_segN += 1u; acc_HN += hs; }
-              if (!LEAN && syn_bm != nullptr) mark_site(is_s, rel + (int)p);
-            }
-          }
-        }
+        joint_finish(wave_or_uniform(read_set(rel)), rel, hget);
       }
     }
+  }
+
+  // The same, up to four columns per call of `read_sets(rels, n, Mv)` (rows in global memory: one
+  // round trip for all of them).
+  template <class ReadSets, class HGet>
+  __device__ void joint_columns_batched(ReadSets read_sets, HGet hget) {
+    int rels[4] = {0, 0, 0, 0};
+    uint32_t nj = 0u;   // wave-uniform: the slots are filled by scalar code
+    auto flush_batch = [&]() {
+      unsigned long long Mv[4] = {0ull, 0ull, 0ull, 0ull};
+      read_sets(rels, nj, Mv);
+#pragma unroll
+      for (uint32_t c = 0; c < 4u; ++c)
+        if (c < nj) joint_finish(wave_or_uniform(Mv[c]), rels[c], hget);
+      nj = 0u;
+    };
+#pragma unroll
+    for (uint32_t it = 0; it < NIT; ++it) {
+      for (uint64_t m = mjoint[it]; m != 0ull; m &= m - 1ull) {
+        const uint32_t owner = (uint32_t)__builtin_ctzll(m);
+        const int rel = __builtin_amdgcn_readlane(endo[it], owner) - 2;
+        if (nj == 0u) rels[0] = rel; else if (nj == 1u) rels[1] = rel; else if (nj == 2u) rels[2] = rel; else rels[3] = rel;
+        if (++nj == 4u) flush_batch();
+      }
+    }
+    if (nj) flush_batch();
   }
 
   // Monomorphic columns and columns with ONE variable position: registers and tables only, so a
@@ -482,9 +505,8 @@ __device__ inline unsigned long long codon_bit(uint32_t x0, uint32_t x1, uint32_
 // ---------------------------------------------------------------- the kernel
 // LEAN: the plan has no row-index list and wants no per-site bitmap (the batch path of the CLI
 // and the bench): those branches, and the scalar registers they pin, are compiled out.
-template <int LB, int STAGE, bool HAS_CDS, bool LEAN>
+template <int STAGE, bool HAS_CDS, bool LEAN>
 __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
-  using G = Geo<LB>;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
   const uint32_t lane = threadIdx.x;
@@ -529,7 +551,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   // per-lane partial sums of this chunk
   uint32_t acc_S = 0u, acc_bad = 0u;
   unsigned long long acc_H = 0ull;
-  CodonPass<LB, LEAN> cp;
+  CodonPass<LEAN> cp;
   if constexpr (HAS_CDS) cp.init(lane, synhist, A, D);
 
   const uint8_t* const mat = A.bases + D.base_off;
@@ -589,19 +611,11 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
 
     // ---------------- tier 1: running AND / OR down the rows
     uint32_t va = 0xFFFFFFFFu, vo = 0u;
-    if constexpr (LB == 4) {
+    {
       const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile8);
 #pragma unroll 8
       for (uint32_t r = 0; r < N; ++r) {
         const uint32_t x = t32[r * 64u + lane];
-        va &= x;
-        vo |= x;
-      }
-    } else {
-      va = 0xFFu;
-#pragma unroll 8
-      for (uint32_t r = 0; r < N; ++r) {
-        const uint32_t x = tile8[r * 64u + lane];
         va &= x;
         vo |= x;
       }
@@ -780,7 +794,7 @@ __device__ inline uint32_t sym6(uint32_t x) {
   return x == 'A' ? 0u : x == 'C' ? 1u : x == 'G' ? 2u : x == 'T' ? 3u : x == '-' ? 4u : x == 'N' ? 5u : 6u;
 }
 
-template <int STAGE>
+template <int STAGE, bool HAS_CDS>
 __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr uint32_t TW = 256u;
@@ -794,7 +808,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   const uint32_t t1 = umin(t0 + A.tiles_per_chunk, n_tiles);
 
   const uint32_t R = A.rows_per_chunk, MAXS = A.max_slots;
-  const TallLayout lo = tall_layout(R, MAXS, A.hist_bins);
+  const TallLayout lo = tall_layout(R, MAXS, A.hist_bins, HAS_CDS);
   uint8_t* const tile8 = lds + lo.tile;
   uint32_t* const list = reinterpret_cast<uint32_t*>(lds + lo.list);
   uint32_t* const cnt = reinterpret_cast<uint32_t*>(lds + lo.cnt);
@@ -802,11 +816,17 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   uint8_t* const xlist = lds + lo.list;                                      // end of tile: sites for the column path
   uint32_t* const colhist = reinterpret_cast<uint32_t*>(lds + lo.list + 256u);   // and its 256 bins
 
+  uint32_t* const hsite = reinterpret_cast<uint32_t*>(lds + lo.hsite);
+  uint32_t* const synhist = reinterpret_cast<uint32_t*>(lds + lo.synhist);
+  const bool cds = HAS_CDS && (D.flags & PFA_FLAG_CDS) != 0u;
+
   const uint32_t nbins = N / 2u, HB = umin(nbins, A.hist_bins);
   const bool mapped = D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
   const uint32_t* const ridx = A.row_idx + (mapped ? D.row_idx_off : 0u);
   const bool multi = N > R;
   for (uint32_t i = lane; i < HB; i += 64u) hist[i] = 0u;
+  if (cds)
+    for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) synhist[i] = 0u;
   // lane r holds the matrix row of the chunk's row r; the next chunk's are fetched while this one is scanned
   uint32_t idx_cur = 0u;
   const uint32_t stride16 = D.row_stride >> 4;
@@ -817,6 +837,13 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   unsigned long long acc_H = 0ull;
   const uint8_t* const mat = A.bases + D.base_off;
   const unsigned long long NN = (unsigned long long)N * N;
+  CodonPass<false> cp;
+  if constexpr (HAS_CDS) cp.init(lane, synhist, A, D);
+  auto hsite_get = [&](int rel) -> uint32_t { return hsite[rel]; };
+  // H and which of A, C, T, G occur (codon base order) of a variable site, for the coding pass
+  auto hsite_put = [&](uint32_t s, unsigned long long hs, uint32_t cA, uint32_t cC, uint32_t cG, uint32_t cT) {
+    hsite[s] = (uint32_t)hs | ((cA ? 1u : 0u) | (cC ? 2u : 0u) | (cT ? 4u : 0u) | (cG ? 8u : 0u)) << 24;
+  };
 
   // second-largest A/C/G/T count (PolyFastA.py:279-281) -> LDS histogram, high bins to global
   auto sfs_add = [&](uint32_t cA, uint32_t cC, uint32_t cG, uint32_t cT) {
@@ -856,6 +883,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     const uint32_t lim = umin(TW, L - site0);
     uint32_t va = 0xFFFFFFFFu, vo = 0u, vd = 0u;   // running AND / OR / XOR words of the rows seen so far
     uint32_t P = 0u, ovf = 0u;                     // variable sites so far; own sites that found no slot
+    bool defer_request = false;
 
     for (uint32_t r0 = 0; r0 < N; r0 += R) {
       const uint32_t Rc = umin(R, N - r0);
@@ -980,8 +1008,18 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       }
       __syncthreads();   // the tile buffer has been read for the last time
       idx_cur = idx_nxt;
-      if (r0 + R < N) stage_chunk(tile, r0 + R, idx_cur);
-      else if (tile + 1u < t1) stage_chunk(tile + 1u, 0u, idx_cur);
+      if (r0 + R < N) {
+        stage_chunk(tile, r0 + R, idx_cur);
+      } else {
+        // Coding units: the register window over the final tier-1 words tells whether the tile has
+        // codon columns that must be read row by row; those reads come from global memory and
+        // would queue behind the next tile's loads, so in that case the request waits for them.
+        if (cds) {
+          cp.window(va, vd, site0, lim);
+          defer_request = (cp.mjoint[0] | cp.mjoint[1]) != 0ull;
+        }
+        if (!defer_request && tile + 1u < t1) stage_chunk(tile + 1u, 0u, idx_cur);
+      }
     }
 
     // ---------------- end of tile: S, bitmap, H and SFS of the slotted sites
@@ -1006,9 +1044,14 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
         if (mode == 0u) {           // exactly two alleles, x and y
           const uint32_t x = ent & 0xFFu, y = x ^ ((ent >> 8) & 0xFFu);
           const uint32_t c1 = c6[0], c2 = c6[1];
-          acc_H += NN - ((unsigned long long)c1 * c1 + (unsigned long long)c2 * c2);
+          const unsigned long long hs = NN - ((unsigned long long)c1 * c1 + (unsigned long long)c2 * c2);
+          acc_H += hs;
           const uint32_t second = (base_clean(x) && base_clean(y)) ? umin(c1, c2) : 0u;
           sfs_add(second, 0u, 0u, second);
+          if (cds) {
+            const uint32_t px = base_clean(x) ? 1u << base_code(x) : 0u, py = base_clean(y) ? 1u << base_code(y) : 0u;
+            hsite[ent >> 24] = (uint32_t)hs | (px | py) << 24;
+          }
         } else if (mode == 1u) {
           const uint32_t cA = c6[0], cC = c6[1], cG = c6[2], cT = c6[3], cGap = c6[4], cNn = c6[5];
           ex = cA + cC + cG + cT + cGap + cNn != N;   // some row holds another byte
@@ -1018,6 +1061,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
                                           (unsigned long long)cGap * cGap + (unsigned long long)cNn * cNn;
             acc_H += NN - sq;
             sfs_add(cA, cC, cG, cT);
+            if (cds) hsite_put(ent >> 24, NN - sq, cA, cC, cG, cT);
           }
         } else {
           ex = true;
@@ -1059,7 +1103,48 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       if (lane == 0u) {
         acc_H += NN - sq;
         sfs_add(colhist['A'], colhist['C'], colhist['G'], colhist['T']);
+        if (cds) hsite_put(s, NN - sq, colhist['A'], colhist['C'], colhist['G'], colhist['T']);
       }
+      __syncthreads();
+    }
+
+    // ---------------- coding units: the codon columns that END in this tile (CodonPass)
+    if (cds) {
+      __syncthreads();   // every hsite entry of the tile is visible
+      // columns with two or three variable positions: their rows come from global memory (one row
+      // per lane); a chunk starts on a codon boundary, so site0 + rel never falls before the unit
+      cp.joint_columns_batched(
+          [&](const int (&rels)[4], uint32_t n, unsigned long long (&Mv)[4]) {
+            // one (unaligned) word per row and column holds the codon; the last codon of a row that
+            // fills its stride is read one byte earlier, so that no load leaves the row
+            uint32_t off[4], sh[4];
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; ++c) {
+              const uint32_t first = site0 + (uint32_t)rels[c < n ? c : 0u];
+              const bool at_end = first + 4u > D.row_stride;
+              off[c] = at_end ? first - 1u : first;
+              sh[c] = at_end ? 8u : 0u;
+            }
+            for (uint32_t r = lane; r < N; r += 64u) {
+              const uint8_t* q = mat + (uint64_t)(mapped ? ridx[r] : r) * D.row_stride;
+              uint32_t w[4];
+#pragma unroll
+              for (uint32_t c = 0; c < 4u; ++c) {
+                uint32_t v = 0u;
+                if (c < n) __builtin_memcpy(&v, q + off[c], 4);
+                w[c] = v >> sh[c];
+              }
+#pragma unroll
+              for (uint32_t c = 0; c < 4u; ++c)
+                if (c < n) Mv[c] |= codon_bit(w[c] & 0xFFu, (w[c] >> 8) & 0xFFu, (w[c] >> 16) & 0xFFu);
+            }
+          },
+          hsite_get);
+      if (defer_request && tile + 1u < t1) stage_chunk(tile + 1u, 0u, idx_cur);
+      cp.mono_and_single_columns(hsite_get);
+      if (tile + 1u == n_tiles) cp.last_tile(L);
+      // H of the last two sites, for the codons that straddle into the next tile
+      if (lane < 2u) hsite[(int)lane - 2] = hsite[TW - 2u + lane];
       __syncthreads();
     }
   }
@@ -1079,6 +1164,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     const uint32_t v = hist[i];
     if (v) atomicAdd(&A.sfs[D.sfs_off + i], v);
   }
+  if (cds) cp.flush(Rz, A.syn_num + (uint64_t)blockIdx.x * PFA_SYN_BINS);
 }
 
 // The device classifier on a list of codon sets (test entry point: pfa_classify_codon_masks_dev)
@@ -1105,7 +1191,6 @@ __global__ void __launch_bounds__(256) slab_to_host_kernel(const uint4* __restri
 }
 
 // ---------------------------------------------------------------- plans
-static constexpr uint32_t kMaxRowsWide = 600u;  // coding plans: LB = 4 (256-site tiles) up to here, LB = 1 above
 static constexpr uint32_t kLdsPerCu = 160u * 1024u;
 static constexpr uint32_t kTallRows = 48u;      // its rows per chunk (upper bound)
 static constexpr uint32_t kTallSlots = 64u;     // its count-table slots per tile (measured: 64 6.03, 96 5.68 TB/s at N = 100)
@@ -1151,17 +1236,17 @@ struct pfa_plan {
 namespace pfa {
 
 static uint32_t tile_sites_for(uint32_t lb, bool /*cds*/) { return 64u * lb; }
-// coding plans above 600 rows fall back to 64-site tiles; non-coding plans switch to the
-// row-chunked kernel long before that and always use 256-site tiles
-static uint32_t lb_for(uint32_t n_max, bool any_cds) { return (!any_cds || n_max <= kMaxRowsWide) ? 4u : 1u; }
+// every plan uses 256-site tiles (lane = 4 sites): units with many rows stream their rows in
+// chunks (scan_tall_kernel) instead of narrowing the tile
+static uint32_t lb_for(uint32_t /*n_max*/, bool /*any_cds*/) { return 4u; }
 static uint32_t env_u32(const char* name, uint32_t dflt) {
   const char* e = getenv(name);
   return e && *e ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
 }
 
-template <int STAGE>
+template <int STAGE, bool CDS>
 static int launch_tall(const pfa_plan* p, const ScanArgs& a) {
-  auto kern = scan_tall_kernel<STAGE>;
+  auto kern = scan_tall_kernel<STAGE, CDS>;
   static uint32_t lds_limit_set = 0;
   if (p->lds_bytes > lds_limit_set) {
     PFA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1174,9 +1259,9 @@ static int launch_tall(const pfa_plan* p, const ScanArgs& a) {
   return PFA_OK;
 }
 
-template <int LB, int STAGE, bool CDS, bool LEAN>
+template <int STAGE, bool CDS, bool LEAN>
 static int launch(const pfa_plan* p, const ScanArgs& a) {
-  auto kern = scan_kernel<LB, STAGE, CDS, LEAN>;
+  auto kern = scan_kernel<STAGE, CDS, LEAN>;
   static uint32_t lds_limit_set = 0;  // per instantiation; one process drives one device
   if (p->lds_bytes > lds_limit_set) {
     PFA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1414,18 +1499,19 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
   p->n_bases_bytes = n_bases_bytes;
   p->use_rowmap = n_row_idx != 0;
   p->lds_bytes = pfa::lds_layout(lb, n_max, any_cds, p->use_rowmap).total;
-  // Non-coding plans with many-row units run the row-chunked kernel.  Keeping all rows of a tile
-  // in LDS is the faster shape while it still fills the CU: at least 5 waves whose tiles add up to
-  // 135 KB of loads in flight (measured: N = 100, 6 waves, 6.45 TB/s against 6.03 row-chunked;
-  // N = 128, 4 waves, 5.84 against 5.88; N = 160, 3 waves, 5.04 against 6.06).
+  // Plans with many-row units run the row-chunked kernel.  Keeping all rows of a tile in LDS is
+  // the faster shape while it still fills the CU: at least 5 waves whose tiles add up to 125 KB of
+  // loads in flight (measured, non-coding: N = 100, 6 waves, 6.45 TB/s against 6.03 row-chunked;
+  // N = 128, 4 waves, 5.84 against 5.88; N = 160, 3 waves, 5.04 against 6.06; coding: N = 100,
+  // 5 waves, 5.13 against 4.78; N = 200, 3 waves, 2.82 against 4.80).
   // Equal chunks of at most kTallRows rows (a multiple of 4: one LDS-DMA instruction moves 4 rows).
   // PFA_TALL_* environment overrides exist for timing experiments.
   bool want_tall = false;
-  if (!any_cds && n_max > 64u) {
+  if (n_max > 64u) {
     const uint32_t waves = pfa::kLdsPerCu / std::max(p->lds_bytes, 1u);
-    want_tall = waves < 5u || (uint64_t)waves * n_max * 256u < 135000ull;
+    want_tall = waves < 5u || (uint64_t)waves * n_max * 256u < 125000ull;
   }
-  if (getenv("PFA_TALL_MIN")) want_tall = !any_cds && n_max > pfa::env_u32("PFA_TALL_MIN", 64u);
+  if (getenv("PFA_TALL_MIN")) want_tall = n_max > pfa::env_u32("PFA_TALL_MIN", 64u) || p->lds_bytes > pfa::kLdsPerCu;
   if (want_tall) {
     const uint32_t rcap = std::min(64u, std::max(8u, pfa::env_u32("PFA_TALL_ROWS", pfa::kTallRows)));
     const uint32_t nc = (n_max + rcap - 1u) / rcap;
@@ -1433,7 +1519,7 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
     p->rows_per_chunk = std::min(64u, std::max(8u, ((n_max + nc - 1u) / nc + 3u) & ~3u));
     p->max_slots = std::min(256u, std::max(16u, pfa::env_u32("PFA_TALL_SLOTS", pfa::kTallSlots)));
     p->hist_bins = std::min(n_max / 2u, 256u);
-    p->lds_bytes = pfa::tall_layout(p->rows_per_chunk, p->max_slots, p->hist_bins).total;
+    p->lds_bytes = pfa::tall_layout(p->rows_per_chunk, p->max_slots, p->hist_bins, any_cds).total;
   }
 
   // chunking: enough single-wave workgroups to fill 256 CUs several times over,
@@ -1538,16 +1624,16 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   int rc;
   // kernel STAGE: 2 = LDS-DMA non-temporal (default), 1 = register staging, 0 = LDS-DMA default cache policy
   const int stage = variant == 1 ? 1 : variant == 2 ? 0 : 2;
-#define PFA_LAUNCH(LB, CDS, LEAN)                                      \
-  (stage == 0 ? pfa::launch<LB, 0, CDS, LEAN>(p, a)                    \
-              : stage == 1 ? pfa::launch<LB, 1, CDS, LEAN>(p, a) : pfa::launch<LB, 2, CDS, LEAN>(p, a))
-  // lean instantiations (no row-index list, no bitmap) exist for the 256-site geometry
+#define PFA_LAUNCH(CDS, LEAN)                                          \
+  (stage == 0 ? pfa::launch<0, CDS, LEAN>(p, a)                        \
+              : stage == 1 ? pfa::launch<1, CDS, LEAN>(p, a) : pfa::launch<2, CDS, LEAN>(p, a))
   const bool lean = !p->use_rowmap && !p->d_var_bm && !p->d_syn_bm;
-  if (p->tall)
-    rc = stage == 0 ? pfa::launch_tall<0>(p, a) : stage == 1 ? pfa::launch_tall<1>(p, a) : pfa::launch_tall<2>(p, a);
-  else if (p->lb == 4 && lean) rc = p->any_cds ? PFA_LAUNCH(4, true, true) : PFA_LAUNCH(4, false, true);
-  else if (p->lb == 4)         rc = p->any_cds ? PFA_LAUNCH(4, true, false) : PFA_LAUNCH(4, false, false);
-  else                         rc = p->any_cds ? PFA_LAUNCH(1, true, false) : PFA_LAUNCH(1, false, false);
+  if (p->tall && p->any_cds)
+    rc = stage == 0 ? pfa::launch_tall<0, true>(p, a) : stage == 1 ? pfa::launch_tall<1, true>(p, a) : pfa::launch_tall<2, true>(p, a);
+  else if (p->tall)
+    rc = stage == 0 ? pfa::launch_tall<0, false>(p, a) : stage == 1 ? pfa::launch_tall<1, false>(p, a) : pfa::launch_tall<2, false>(p, a);
+  else if (lean) rc = p->any_cds ? PFA_LAUNCH(true, true) : PFA_LAUNCH(false, true);
+  else           rc = p->any_cds ? PFA_LAUNCH(true, false) : PFA_LAUNCH(false, false);
 #undef PFA_LAUNCH
   if (rc != PFA_OK) return rc;
   PFA_HIP(hipEventRecord(p->ev1[slot], st));

@@ -119,8 +119,9 @@ def test_row_subsets_match_oracle(gpu):
 
 
 @pytest.mark.parametrize("n_rows", [601, 1000, 2048])
-def test_narrow_tiles_many_rows(gpu, n_rows):
-    """More than 600 rows switches the plan to 64-site tiles (one byte per lane)."""
+def test_many_rows_single_alignment(gpu, n_rows):
+    """Hundreds to thousands of rows, coding or not: the row-chunked kernel (rows streamed through
+    LDS in chunks, same 256-site tiles)."""
     p = synth.make_params(n_rows, 0.02)
     for L, coding in ((700, False), (333, True)):
         m = synth.synth_alignment(5, n_rows, L, p, coding=coding)

@@ -91,7 +91,8 @@ def test_random_batches_lean_kernels(gpu, seed, cds):
 
 
 def test_random_many_rows(gpu):
-    """coding plans whose largest unit has more than 600 rows run the 64-site-tile kernel for every unit"""
+    """coding plans with many-row units run the row-chunked kernel for every unit (coding pass fed from
+    the slot tables, joint codon columns read back from global memory)"""
     rng = np.random.default_rng(99)
     b = scan.Batch()
     units = []
