@@ -167,6 +167,11 @@ __device__ inline uint32_t quad_sum(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
   return v;
 }
+// Workgroups are ONE wavefront: "synchronising" it only means ordering its LDS traffic (lanes
+// exchange data through LDS).  __syncthreads() would also wait for every global load in flight
+// (s_waitcnt vmcnt(0)), i.e. for the tile that was just requested ahead of time.
+__device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // value of the previous lane (lane 0: 0): one DPP move instead of a ds_bpermute
 __device__ inline uint32_t wave_shr1(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);   // wave_shr:1
@@ -487,7 +492,7 @@ struct CodonPass {
       if (acc_HN) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H_N), acc_HN);
       if (acc_syn1) atomicAdd(&syn_num_unit[1], acc_syn1);
     }
-    __syncthreads();
+    wave_lds_sync();
     for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) {
       const uint32_t v = synhist[i];
       if (v) atomicAdd(&syn_num_unit[i], v);
@@ -546,7 +551,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   {
     for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) synhist[i] = 0u;
   }
-  __syncthreads();
+  wave_lds_sync();
 
   // per-lane partial sums of this chunk
   uint32_t acc_S = 0u, acc_bad = 0u;
@@ -607,7 +612,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     const uint32_t site0 = tile * TW;
     const uint32_t lim = umin(TW, L - site0);  // valid sites of this tile
     if constexpr (STAGE != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    wave_lds_sync();
 
     // ---------------- tier 1: running AND / OR down the rows
     uint32_t va = 0xFFFFFFFFu, vo = 0u;
@@ -636,7 +641,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     }
     P = __builtin_amdgcn_readfirstlane(P);
     acc_S += (lane == 0u) ? P : 0u;
-    __syncthreads();
+    wave_lds_sync();
 
     // ---------------- tier 2: exact allele counts of the variable sites
     // 4 lanes per site walk its column.  Fast path: x = the byte of row 0, y = x ^ (XOR byte of
@@ -719,7 +724,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
 
     // ---------------- coding sequences: the codon columns that END in this tile (CodonPass)
     if (cds) {
-      __syncthreads();   // tier 2's hsite entries are visible
+      wave_lds_sync();   // tier 2's hsite entries are visible
       cp.window(va, vd, site0, lim);
       // columns with two or three variable positions: one row per lane out of the LDS tile; the
       // one or two sites a codon reaches back into the previous tile come from `carry`
@@ -740,7 +745,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
         carry[2u * i + 1u] = tile8[i * G::WW + G::WW - 1u];
       }
       // ---- nothing below reads the tile buffer: request the next tile now
-      __syncthreads();
+      wave_lds_sync();
       if (tile + 1u < t1) stage(tile + 1u);
       cp.mono_and_single_columns(hsite_get);
       if (tile + 1u == n_tiles) cp.last_tile(L);
@@ -750,7 +755,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
         else hsite32[(int)lane - 2] = hsite32[G::WW - 2u + lane];
       }
     } else {
-      __syncthreads();   // every read of the tile buffer is done: request the next tile
+      wave_lds_sync();   // every read of the tile buffer is done: request the next tile
       if (tile + 1u < t1) stage(tile + 1u);
     }
   }
@@ -765,7 +770,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     if (acc_bad) atomicAdd(&R->sfs_bad, acc_bad);
     if (acc_H) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H), acc_H);
   }
-  __syncthreads();
+  wave_lds_sync();
   for (uint32_t i = lane; i < nbins; i += 64u) {
     const uint32_t v = hist[i];
     if (v) atomicAdd(&A.sfs[D.sfs_off + i], v);
@@ -831,7 +836,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   uint32_t idx_cur = 0u;
   const uint32_t stride16 = D.row_stride >> 4;
   if (mapped && lane < umin(R, N)) idx_cur = ridx[lane] * stride16;
-  __syncthreads();
+  wave_lds_sync();
 
   uint32_t acc_S = 0u, acc_bad = 0u;
   unsigned long long acc_H = 0ull;
@@ -852,6 +857,49 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     if (second == 0u) acc_bad += 1u;
     else if (second - 1u < HB) atomicAdd(&hist[second - 1u], 1u);
     else atomicAdd(&A.sfs[D.sfs_off + second - 1u], 1u);
+  };
+
+  // Coding units: the rows of a codon column with two or three variable positions are no longer
+  // in LDS when the column is recognised, so they are read back from global memory — one
+  // (unaligned) word per row holds the codon.  With at most 64 * JR rows and at most four such
+  // columns in a tile, the words are loaded into registers at the end of the tile and consumed
+  // when the first chunk of the NEXT tile has arrived: the read-back rides on that wait instead
+  // of costing a memory round trip of its own.
+  constexpr uint32_t JR = 4u;
+  const bool jdefer_ok = cds && N <= 64u * JR;
+  uint32_t jrow16[JR] = {0u, 0u, 0u, 0u};            // byte offset / 16 of rows lane, lane + 64, ...
+  if (jdefer_ok) {
+#pragma unroll
+    for (uint32_t i = 0; i < JR; ++i) {
+      const uint32_t r = lane + 64u * i;
+      if (r < N) jrow16[i] = (mapped ? ridx[r] : r) * stride16;
+    }
+  }
+  uint32_t jn = 0u;                                  // pending columns (wave-uniform)
+  int jrel[4] = {0, 0, 0, 0};
+  uint32_t jsh[4] = {0u, 0u, 0u, 0u};
+  uint32_t jw[4][JR] = {};
+  // word offset of a codon in its row: the last codon of a row that fills its stride is read one
+  // byte earlier, so that no load leaves the row
+  auto codon_word_at = [&](uint32_t first_site, uint32_t& off, uint32_t& sh) {
+    const bool at_end = first_site + 4u > D.row_stride;
+    off = at_end ? first_site - 1u : first_site;
+    sh = at_end ? 8u : 0u;
+  };
+  auto finish_pending = [&]() {
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; ++c) {
+      if (c < jn) {
+        unsigned long long Mv = 0ull;
+#pragma unroll
+        for (uint32_t i = 0; i < JR; ++i) {
+          const uint32_t w = jw[c][i] >> jsh[c];
+          if (lane + 64u * i < N) Mv |= codon_bit(w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu);
+        }
+        cp.joint_finish(wave_or_uniform(Mv), jrel[c], hsite_get);
+      }
+    }
+    jn = 0u;
   };
 
   // ---------------- stage rows [r0, r0 + Rc) x 256 sites of a tile (asynchronous for LDS-DMA)
@@ -883,7 +931,8 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     const uint32_t lim = umin(TW, L - site0);
     uint32_t va = 0xFFFFFFFFu, vo = 0u, vd = 0u;   // running AND / OR / XOR words of the rows seen so far
     uint32_t P = 0u, ovf = 0u;                     // variable sites so far; own sites that found no slot
-    bool defer_request = false;
+    bool defer_request = false, readback_later = false;
+    uint32_t n_joint = 0u;
 
     for (uint32_t r0 = 0; r0 < N; r0 += R) {
       const uint32_t Rc = umin(R, N - r0);
@@ -893,7 +942,15 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
         if (lane < umin(R, N - r0n)) idx_nxt = ridx[r0n + lane] * stride16;
       }
       if constexpr (STAGE != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      wave_lds_sync();
+      if (cds && r0 == 0u && tile > t0) {
+        // the previous tile's read-back has arrived with this chunk; its hsite entries are still in
+        // place (cp.site0 too: the window of this tile is computed after its last chunk)
+        if (jn) finish_pending();
+        // H of the previous tile's last two sites, for the codons that straddle into this tile
+        if (lane < 2u) hsite[(int)lane - 2] = hsite[TW - 2u + lane];
+        wave_lds_sync();
+      }
 
       // ---------------- tier 1 on the chunk, folded into the running words
       uint32_t ca = 0xFFFFFFFFu, co = 0u;
@@ -938,7 +995,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       vd = nvd;
       P = __builtin_amdgcn_readfirstlane(P);
       const uint32_t Pc = umin(P, MAXS);
-      __syncthreads();
+      wave_lds_sync();
 
       // ---------------- tier 2: the chunk's rows of every slotted site
       const uint32_t slot16 = lane >> 2, ph = lane & 3u;
@@ -1006,7 +1063,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
           }
         }
       }
-      __syncthreads();   // the tile buffer has been read for the last time
+      wave_lds_sync();   // the tile buffer has been read for the last time
       idx_cur = idx_nxt;
       if (r0 + R < N) {
         stage_chunk(tile, r0 + R, idx_cur);
@@ -1016,7 +1073,9 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
         // would queue behind the next tile's loads, so in that case the request waits for them.
         if (cds) {
           cp.window(va, vd, site0, lim);
-          defer_request = (cp.mjoint[0] | cp.mjoint[1]) != 0ull;
+          n_joint = (uint32_t)__popcll(cp.mjoint[0]) + (uint32_t)__popcll(cp.mjoint[1]);
+          readback_later = jdefer_ok && n_joint != 0u && n_joint <= 4u && tile + 1u < t1;
+          defer_request = n_joint != 0u && !readback_later;
         }
         if (!defer_request && tile + 1u < t1) stage_chunk(tile + 1u, 0u, idx_cur);
       }
@@ -1079,20 +1138,20 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       X += (uint32_t)__popcll(m);
     }
     X = __builtin_amdgcn_readfirstlane(X);
-    __syncthreads();
+    wave_lds_sync();
 
     // ---------------- column path: exact allele counts of one site from global memory
     for (uint32_t i = 0; i < X; ++i) {
       const uint32_t s = xlist[i];
 #pragma unroll
       for (uint32_t k = 0; k < 4u; ++k) colhist[lane + 64u * k] = 0u;
-      __syncthreads();
+      wave_lds_sync();
       const uint8_t* gcol = mat + site0 + s;
       for (uint32_t r = lane; r < N; r += 64u) {
         const uint32_t row = mapped ? ridx[r] : r;
         atomicAdd(&colhist[gcol[(uint64_t)row * D.row_stride]], 1u);
       }
-      __syncthreads();
+      wave_lds_sync();
       unsigned long long sq = 0ull;
 #pragma unroll
       for (uint32_t k = 0; k < 4u; ++k) {
@@ -1105,47 +1164,62 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
         sfs_add(colhist['A'], colhist['C'], colhist['G'], colhist['T']);
         if (cds) hsite_put(s, NN - sq, colhist['A'], colhist['C'], colhist['G'], colhist['T']);
       }
-      __syncthreads();
+      wave_lds_sync();
     }
 
     // ---------------- coding units: the codon columns that END in this tile (CodonPass)
     if (cds) {
-      __syncthreads();   // every hsite entry of the tile is visible
+      wave_lds_sync();   // every hsite entry of the tile is visible
       // columns with two or three variable positions: their rows come from global memory (one row
       // per lane); a chunk starts on a codon boundary, so site0 + rel never falls before the unit
-      cp.joint_columns_batched(
-          [&](const int (&rels)[4], uint32_t n, unsigned long long (&Mv)[4]) {
-            // one (unaligned) word per row and column holds the codon; the last codon of a row that
-            // fills its stride is read one byte earlier, so that no load leaves the row
-            uint32_t off[4], sh[4];
+      if (readback_later) {
+        // issue the loads now, finish when the next tile's first chunk has arrived
+        uint64_t m0 = cp.mjoint[0], m1 = cp.mjoint[1];
+        jn = n_joint;
 #pragma unroll
-            for (uint32_t c = 0; c < 4u; ++c) {
-              const uint32_t first = site0 + (uint32_t)rels[c < n ? c : 0u];
-              const bool at_end = first + 4u > D.row_stride;
-              off[c] = at_end ? first - 1u : first;
-              sh[c] = at_end ? 8u : 0u;
+        for (uint32_t c = 0; c < 4u; ++c) {
+          if (c < n_joint) {                                  // wave-uniform
+            const bool second = m0 == 0ull;
+            const uint64_t m = second ? m1 : m0;
+            const uint32_t owner = (uint32_t)__builtin_ctzll(m);
+            const int rel = __builtin_amdgcn_readlane(second ? cp.endo[1] : cp.endo[0], owner) - 2;
+            if (second) m1 &= m1 - 1ull; else m0 &= m0 - 1ull;
+            uint32_t off;
+            codon_word_at(site0 + (uint32_t)rel, off, jsh[c]);
+            jrel[c] = rel;
+#pragma unroll
+            for (uint32_t i = 0; i < JR; ++i) {
+              jw[c][i] = 0u;
+              if (lane + 64u * i < N) __builtin_memcpy(&jw[c][i], mat + ((uint64_t)jrow16[i] << 4) + off, 4);
             }
-            for (uint32_t r = lane; r < N; r += 64u) {
-              const uint8_t* q = mat + (uint64_t)(mapped ? ridx[r] : r) * D.row_stride;
-              uint32_t w[4];
+          }
+        }
+      } else if (n_joint) {
+        cp.joint_columns_batched(
+            [&](const int (&rels)[4], uint32_t n, unsigned long long (&Mv)[4]) {
+              uint32_t off[4], sh[4];
 #pragma unroll
-              for (uint32_t c = 0; c < 4u; ++c) {
-                uint32_t v = 0u;
-                if (c < n) __builtin_memcpy(&v, q + off[c], 4);
-                w[c] = v >> sh[c];
+              for (uint32_t c = 0; c < 4u; ++c) codon_word_at(site0 + (uint32_t)rels[c < n ? c : 0u], off[c], sh[c]);
+              for (uint32_t r = lane; r < N; r += 64u) {
+                const uint8_t* q = mat + (uint64_t)(mapped ? ridx[r] : r) * D.row_stride;
+                uint32_t w[4];
+#pragma unroll
+                for (uint32_t c = 0; c < 4u; ++c) {
+                  uint32_t v = 0u;
+                  if (c < n) __builtin_memcpy(&v, q + off[c], 4);
+                  w[c] = v >> sh[c];
+                }
+#pragma unroll
+                for (uint32_t c = 0; c < 4u; ++c)
+                  if (c < n) Mv[c] |= codon_bit(w[c] & 0xFFu, (w[c] >> 8) & 0xFFu, (w[c] >> 16) & 0xFFu);
               }
-#pragma unroll
-              for (uint32_t c = 0; c < 4u; ++c)
-                if (c < n) Mv[c] |= codon_bit(w[c] & 0xFFu, (w[c] >> 8) & 0xFFu, (w[c] >> 16) & 0xFFu);
-            }
-          },
-          hsite_get);
+            },
+            hsite_get);
+      }
       if (defer_request && tile + 1u < t1) stage_chunk(tile + 1u, 0u, idx_cur);
       cp.mono_and_single_columns(hsite_get);
       if (tile + 1u == n_tiles) cp.last_tile(L);
-      // H of the last two sites, for the codons that straddle into the next tile
-      if (lane < 2u) hsite[(int)lane - 2] = hsite[TW - 2u + lane];
-      __syncthreads();
+      wave_lds_sync();
     }
   }
 
@@ -1159,7 +1233,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     if (acc_bad) atomicAdd(&Rz->sfs_bad, acc_bad);
     if (acc_H) atomicAdd(reinterpret_cast<unsigned long long*>(&Rz->H), acc_H);
   }
-  __syncthreads();
+  wave_lds_sync();
   for (uint32_t i = lane; i < HB; i += 64u) {
     const uint32_t v = hist[i];
     if (v) atomicAdd(&A.sfs[D.sfs_off + i], v);
@@ -1623,7 +1697,10 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   PFA_HIP(hipEventRecord(p->ev0[slot], st));
   int rc;
   // kernel STAGE: 2 = LDS-DMA non-temporal (default), 1 = register staging, 0 = LDS-DMA default cache policy
-  const int stage = variant == 1 ? 1 : variant == 2 ? 0 : 2;
+  // (the coding variant of the row-chunked kernel reads a few columns a second time — its joint
+  // codon columns — so its tiles are loaded with the default policy and stay cacheable: 5.15 against
+  // 4.74 TB/s at N = 200)
+  const int stage = variant == 1 ? 1 : (variant == 2 || (p->tall && p->any_cds)) ? 0 : 2;
 #define PFA_LAUNCH(CDS, LEAN)                                          \
   (stage == 0 ? pfa::launch<0, CDS, LEAN>(p, a)                        \
               : stage == 1 ? pfa::launch<1, CDS, LEAN>(p, a) : pfa::launch<2, CDS, LEAN>(p, a))
