@@ -123,7 +123,7 @@ struct ScanArgs {
 };
 
 struct TallLayout {
-  uint32_t tile, list, cnt, hist, hsite, synhist, total;
+  uint32_t tile, list, cnt, hist, hsite, synhist, cslots, total;
 };
 
 PFA_HD inline TallLayout tall_layout(uint32_t rows_per_chunk, uint32_t max_slots, uint32_t hist_bins, bool cds) {
@@ -139,7 +139,9 @@ PFA_HD inline TallLayout tall_layout(uint32_t rows_per_chunk, uint32_t max_slots
   // the last two sites of the previous tile, and the bins of synonymous-site numerators
   o.hsite = o.hist + round16(hist_bins * 4u + 4u) + (cds ? 16u : 0u);
   o.synhist = o.hsite + (cds ? 256u * 4u : 0u);
-  o.total = o.synhist + (cds ? round16(PFA_SYN_BINS * 4u) : 0u);
+  // codon slots: the codon sets of up to 8 joint columns of the tile, tracked chunk by chunk
+  o.cslots = o.synhist + (cds ? round16(PFA_SYN_BINS * 4u) : 0u);
+  o.total = o.cslots + (cds ? 32u + 64u : 0u);
   return o;
 }
 
@@ -859,47 +861,37 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     else atomicAdd(&A.sfs[D.sfs_off + second - 1u], 1u);
   };
 
-  // Coding units: the rows of a codon column with two or three variable positions are no longer
-  // in LDS when the column is recognised, so they are read back from global memory — one
-  // (unaligned) word per row holds the codon.  With at most 64 * JR rows and at most four such
-  // columns in a tile, the words are loaded into registers at the end of the tile and consumed
-  // when the first chunk of the NEXT tile has arrived: the read-back rides on that wait instead
-  // of costing a memory round trip of its own.
-  constexpr uint32_t JR = 4u;
-  const bool jdefer_ok = cds && N <= 64u * JR;
-  uint32_t jrow16[JR] = {0u, 0u, 0u, 0u};            // byte offset / 16 of rows lane, lane + 64, ...
-  if (jdefer_ok) {
-#pragma unroll
-    for (uint32_t i = 0; i < JR; ++i) {
-      const uint32_t r = lane + 64u * i;
-      if (r < N) jrow16[i] = (mapped ? ridx[r] : r) * stride16;
-    }
-  }
-  uint32_t jn = 0u;                                  // pending columns (wave-uniform)
-  int jrel[4] = {0, 0, 0, 0};
-  uint32_t jsh[4] = {0u, 0u, 0u, 0u};
-  uint32_t jw[4][JR] = {};
-  // word offset of a codon in its row: the last codon of a row that fills its stride is read one
-  // byte earlier, so that no load leaves the row
+  // word offset of a codon in its row (read-back of columns that no codon slot tracked): the last
+  // codon of a row that fills its stride is read one byte earlier, so that no load leaves the row
   auto codon_word_at = [&](uint32_t first_site, uint32_t& off, uint32_t& sh) {
     const bool at_end = first_site + 4u > D.row_stride;
     off = at_end ? first_site - 1u : first_site;
     sh = at_end ? 8u : 0u;
   };
-  auto finish_pending = [&]() {
+
+  // Codon slots (coding units).  The rows of a column with two or three variable positions are gone
+  // from LDS by the time the column is recognised — unless its codon set is accumulated on the
+  // way: from the chunk in which the column's SECOND position starts to vary, every chunk adds the
+  // codons of its rows (one row per lane, OR-reduced).  The rows before that chunk held the
+  // consensus byte everywhere except at the one position that already varied, so their codons are
+  // the consensus codon with that position's alleles substituted — known from its count slot.
+  // Columns that cannot be tracked (they reach back into the previous tile, the slot table is full,
+  // a position without usable counts) are read back from memory at the end of the tile.
+  constexpr uint32_t CS = 8u;
+  int* const cs_end = reinterpret_cast<int*>(lds + lo.cslots);                                   // tile-relative end site
+  unsigned long long* const cs_set = reinterpret_cast<unsigned long long*>(lds + lo.cslots + 32u);
+  int endoT[2] = {-1, -1};         // this lane's candidate codon columns of the tile (as in CodonPass::window)
+  uint32_t shT[2] = {0u, 0u};
+  auto joint_ballots = [&](uint32_t vdrun, uint64_t (&jb)[2]) {
+    uint32_t pd = wave_shr1(vdrun);
+    if (lane == 0u) pd = cp.carry_vd;
+    const unsigned long long Wd = (unsigned long long)pd | (unsigned long long)vdrun << 32;
 #pragma unroll
-    for (uint32_t c = 0; c < 4u; ++c) {
-      if (c < jn) {
-        unsigned long long Mv = 0ull;
-#pragma unroll
-        for (uint32_t i = 0; i < JR; ++i) {
-          const uint32_t w = jw[c][i] >> jsh[c];
-          if (lane + 64u * i < N) Mv |= codon_bit(w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu);
-        }
-        cp.joint_finish(wave_or_uniform(Mv), jrel[c], hsite_get);
-      }
+    for (uint32_t it = 0; it < 2u; ++it) {
+      const uint32_t dv = (uint32_t)(Wd >> shT[it]) & 0xFFFFFFu;
+      const uint32_t nvar = (uint32_t)((dv & 0xFFu) != 0u) + (uint32_t)((dv & 0xFF00u) != 0u) + (uint32_t)((dv & 0xFF0000u) != 0u);
+      jb[it] = __ballot(endoT[it] >= 0 && nvar >= 2u);
     }
-    jn = 0u;
   };
 
   // ---------------- stage rows [r0, r0 + Rc) x 256 sites of a tile (asynchronous for LDS-DMA)
@@ -931,8 +923,20 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     const uint32_t lim = umin(TW, L - site0);
     uint32_t va = 0xFFFFFFFFu, vo = 0u, vd = 0u;   // running AND / OR / XOR words of the rows seen so far
     uint32_t P = 0u, ovf = 0u;                     // variable sites so far; own sites that found no slot
-    bool defer_request = false, readback_later = false;
+    bool defer_request = false;
     uint32_t n_joint = 0u;
+    uint32_t ncs = 0u;                       // codon slots in use (wave-uniform)
+    uint64_t jb_prev[2] = {0ull, 0ull};      // columns that were joint after the previous chunk
+    uint64_t tracked[2] = {0ull, 0ull};      // joint columns of the finished tile whose set sits in a slot
+    if (cds) {
+      const uint32_t o1 = (5u - (site0 + 4u * lane) % 3u) % 3u;
+#pragma unroll
+      for (uint32_t it = 0; it < 2u; ++it) {
+        const uint32_t o = o1 + 3u * it;
+        endoT[it] = (o < 4u && 4u * lane + o < lim) ? (int)(4u * lane + o) : -1;
+        shT[it] = 8u * (2u + (o & 3u));
+      }
+    }
 
     for (uint32_t r0 = 0; r0 < N; r0 += R) {
       const uint32_t Rc = umin(R, N - r0);
@@ -944,9 +948,6 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       if constexpr (STAGE != 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wave_lds_sync();
       if (cds && r0 == 0u && tile > t0) {
-        // the previous tile's read-back has arrived with this chunk; its hsite entries are still in
-        // place (cp.site0 too: the window of this tile is computed after its last chunk)
-        if (jn) finish_pending();
         // H of the previous tile's last two sites, for the codons that straddle into this tile
         if (lane < 2u) hsite[(int)lane - 2] = hsite[TW - 2u + lane];
         wave_lds_sync();
@@ -990,12 +991,73 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
           P += (uint32_t)__popcll(m);
         }
       }
+      const uint32_t va_pre = va, vd_pre = vd, P_prev = umin(P, MAXS);   // state before this chunk
       va = nva;
       vo = nvo;
       vd = nvd;
       P = __builtin_amdgcn_readfirstlane(P);
       const uint32_t Pc = umin(P, MAXS);
       wave_lds_sync();
+
+      // ---------------- coding units: columns that turn joint in this chunk get a codon slot
+      if (cds) {
+        uint64_t jb_now[2];
+        joint_ballots(nvd, jb_now);
+#pragma unroll
+        for (uint32_t it = 0; it < 2u; ++it) {
+          for (uint64_t m = jb_now[it] & ~jb_prev[it]; m != 0ull; m &= m - 1ull) {
+            const int end = __builtin_amdgcn_readlane(endoT[it], (uint32_t)__builtin_ctzll(m));
+            const int rel = end - 2;
+            if (rel < 0 || ncs >= CS) continue;          // read back at the end of the tile
+            // the distinct clean codons of the rows before this chunk: per position the alleles seen so far
+            unsigned long long S = 0ull;
+            bool usable = true;
+            if (r0 != 0u) {
+              uint32_t pm[3] = {0u, 0u, 0u};             // presence masks over A, C, T, G (codon base order)
+#pragma unroll
+              for (uint32_t q = 0; q < 3u; ++q) {
+                const uint32_t sq = (uint32_t)rel + q;
+                const uint32_t dbyte = ((uint32_t)__builtin_amdgcn_readlane((int)vd_pre, sq >> 2) >> (8u * (sq & 3u))) & 0xFFu;
+                const uint32_t abyte = ((uint32_t)__builtin_amdgcn_readlane((int)va_pre, sq >> 2) >> (8u * (sq & 3u))) & 0xFFu;
+                if (dbyte == 0u) {                       // every earlier row holds the consensus byte
+                  pm[q] = base_clean(abyte) ? 1u << base_code(abyte) : 0u;
+                } else {                                 // the site's count slot, as it stood before this chunk
+                  uint64_t hit = 0ull;
+                  uint32_t base = 0u;
+                  for (; base < P_prev && hit == 0ull; base += 64u)
+                    hit = __ballot(base + lane < P_prev && (list[base + lane] >> 24) == sq);
+                  if (hit == 0ull) { usable = false; continue; }
+                  const uint32_t j = base - 64u + (uint32_t)__builtin_ctzll(hit);
+                  const uint32_t ent = list[j];
+                  const uint32_t mode = (ent >> 16) & 0xFFu;
+                  const uint32_t* c6 = cnt + j * 6u;
+                  if (mode == 0u) {
+                    const uint32_t x = ent & 0xFFu, y = x ^ ((ent >> 8) & 0xFFu);
+                    pm[q] = ((c6[0] != 0u && base_clean(x)) ? 1u << base_code(x) : 0u) |
+                            ((c6[1] != 0u && base_clean(y)) ? 1u << base_code(y) : 0u);
+                  } else if (mode == 1u) {               // counters A C G T - N
+                    pm[q] = (c6[0] ? 1u : 0u) | (c6[1] ? 2u : 0u) | (c6[3] ? 4u : 0u) | (c6[2] ? 8u : 0u);
+                  } else {
+                    usable = false;
+                  }
+                }
+              }
+#pragma unroll
+              for (uint32_t e0 = 0; e0 < 4u; ++e0)
+#pragma unroll
+                for (uint32_t e1 = 0; e1 < 4u; ++e1)
+#pragma unroll
+                  for (uint32_t e2 = 0; e2 < 4u; ++e2)
+                    if (((pm[0] >> e0) & (pm[1] >> e1) & (pm[2] >> e2) & 1u) != 0u) S |= 1ull << (16u * e0 + 4u * e1 + e2);
+            }
+            if (!usable) continue;
+            if (lane == 0u) { cs_end[ncs] = end; cs_set[ncs] = S; }
+            ++ncs;
+          }
+          jb_prev[it] = jb_now[it];
+        }
+        wave_lds_sync();
+      }
 
       // ---------------- tier 2: the chunk's rows of every slotted site
       const uint32_t slot16 = lane >> 2, ph = lane & 3u;
@@ -1063,19 +1125,38 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
           }
         }
       }
+      // ---------------- coding units: the chunk's rows of every codon slot (one row per lane)
+      for (uint32_t k = 0; k < ncs; ++k) {
+        const uint32_t first = (uint32_t)(cs_end[k] - 2);
+        const uint8_t* q = tile8 + lane * TW + first;
+        const unsigned long long M = wave_or_uniform(lane < Rc ? codon_bit(q[0], q[1], q[2]) : 0ull);
+        if (lane == 0u) cs_set[k] |= M;
+      }
       wave_lds_sync();   // the tile buffer has been read for the last time
       idx_cur = idx_nxt;
       if (r0 + R < N) {
         stage_chunk(tile, r0 + R, idx_cur);
       } else {
-        // Coding units: the register window over the final tier-1 words tells whether the tile has
-        // codon columns that must be read row by row; those reads come from global memory and
-        // would queue behind the next tile's loads, so in that case the request waits for them.
+        // Coding units: the register window over the final tier-1 words gives the tile's codon
+        // columns with two or three variable positions.
         if (cds) {
           cp.window(va, vd, site0, lim);
+          // joint columns whose codon set sits in a slot need no read-back
+#pragma unroll
+          for (uint32_t it = 0; it < 2u; ++it) {
+            for (uint64_t m = cp.mjoint[it]; m != 0ull; m &= m - 1ull) {
+              const uint32_t owner = (uint32_t)__builtin_ctzll(m);
+              const int end = __builtin_amdgcn_readlane(cp.endo[it], owner);
+              bool found = false;
+              for (uint32_t k = 0; k < ncs; ++k) found = found || cs_end[k] == end;
+              if (found) tracked[it] |= 1ull << owner;
+            }
+            cp.mjoint[it] &= ~tracked[it];
+          }
           n_joint = (uint32_t)__popcll(cp.mjoint[0]) + (uint32_t)__popcll(cp.mjoint[1]);
-          readback_later = jdefer_ok && n_joint != 0u && n_joint <= 4u && tile + 1u < t1;
-          defer_request = n_joint != 0u && !readback_later;
+          // the others (rare) are read back from global memory; those reads would queue behind the
+          // next tile's loads, so in that case the request waits for them
+          defer_request = n_joint != 0u;
         }
         if (!defer_request && tile + 1u < t1) stage_chunk(tile + 1u, 0u, idx_cur);
       }
@@ -1172,29 +1253,17 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       wave_lds_sync();   // every hsite entry of the tile is visible
       // columns with two or three variable positions: their rows come from global memory (one row
       // per lane); a chunk starts on a codon boundary, so site0 + rel never falls before the unit
-      if (readback_later) {
-        // issue the loads now, finish when the next tile's first chunk has arrived
-        uint64_t m0 = cp.mjoint[0], m1 = cp.mjoint[1];
-        jn = n_joint;
 #pragma unroll
-        for (uint32_t c = 0; c < 4u; ++c) {
-          if (c < n_joint) {                                  // wave-uniform
-            const bool second = m0 == 0ull;
-            const uint64_t m = second ? m1 : m0;
-            const uint32_t owner = (uint32_t)__builtin_ctzll(m);
-            const int rel = __builtin_amdgcn_readlane(second ? cp.endo[1] : cp.endo[0], owner) - 2;
-            if (second) m1 &= m1 - 1ull; else m0 &= m0 - 1ull;
-            uint32_t off;
-            codon_word_at(site0 + (uint32_t)rel, off, jsh[c]);
-            jrel[c] = rel;
-#pragma unroll
-            for (uint32_t i = 0; i < JR; ++i) {
-              jw[c][i] = 0u;
-              if (lane + 64u * i < N) __builtin_memcpy(&jw[c][i], mat + ((uint64_t)jrow16[i] << 4) + off, 4);
-            }
-          }
+      for (uint32_t it = 0; it < 2u; ++it) {
+        for (uint64_t m = tracked[it]; m != 0ull; m &= m - 1ull) {
+          const int end = __builtin_amdgcn_readlane(cp.endo[it], (uint32_t)__builtin_ctzll(m));
+          unsigned long long M = 0ull;
+          for (uint32_t k = 0; k < ncs; ++k)
+            if (cs_end[k] == end) M = cs_set[k];
+          cp.joint_finish(M, end - 2, hsite_get);
         }
-      } else if (n_joint) {
+      }
+      if (n_joint) {
         cp.joint_columns_batched(
             [&](const int (&rels)[4], uint32_t n, unsigned long long (&Mv)[4]) {
               uint32_t off[4], sh[4];
@@ -1697,10 +1766,7 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   PFA_HIP(hipEventRecord(p->ev0[slot], st));
   int rc;
   // kernel STAGE: 2 = LDS-DMA non-temporal (default), 1 = register staging, 0 = LDS-DMA default cache policy
-  // (the coding variant of the row-chunked kernel reads a few columns a second time — its joint
-  // codon columns — so its tiles are loaded with the default policy and stay cacheable: 5.15 against
-  // 4.74 TB/s at N = 200)
-  const int stage = variant == 1 ? 1 : (variant == 2 || (p->tall && p->any_cds)) ? 0 : 2;
+  const int stage = variant == 1 ? 1 : variant == 2 ? 0 : 2;
 #define PFA_LAUNCH(CDS, LEAN)                                          \
   (stage == 0 ? pfa::launch<0, CDS, LEAN>(p, a)                        \
               : stage == 1 ? pfa::launch<1, CDS, LEAN>(p, a) : pfa::launch<2, CDS, LEAN>(p, a))
