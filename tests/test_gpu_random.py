@@ -172,3 +172,37 @@ def test_too_many_rows_is_refused(gpu):
     m[7, 3] = 67
     r = scan.scan_matrix(m).results[0]
     assert (int(r["seg_sites"]), int(r["H"])) == (1, 2049 * 2049 - 2048 * 2048 - 1)
+
+
+@pytest.mark.parametrize("rows_per_chunk,slots,seed", [(8, 16, 0), (12, 64, 1), (36, 64, 2), (8, 256, 3), (64, 32, 4)])
+def test_tall_kernel_coding_forced_on_small_units(gpu, monkeypatch, rows_per_chunk, slots, seed):
+    """The coding variant of the row-chunked kernel forced onto units of any size, with tiny chunks
+    (columns turn joint in early, middle and late chunks: codon slots seeded from count slots in
+    every mode), tiny count-slot tables (positions without usable counts: read-back), mutation
+    rates from 0 to 30 % (more joint columns per tile than codon slots: read-back), odd alphabets
+    (unclean codons), lengths that are not multiples of 3 or 256 (columns straddling tiles), row
+    subsets in any order."""
+    monkeypatch.setenv("PFA_TALL_MIN", "0")
+    monkeypatch.setenv("PFA_TALL_ROWS", str(rows_per_chunk))
+    monkeypatch.setenv("PFA_TALL_SLOTS", str(slots))
+    rng = np.random.default_rng(500 + seed)
+    b = scan.Batch(stride_align=int(rng.choice([16, 128])))
+    units = []
+    for _ in range(36):
+        n = int(rng.choice([1, 2, 3, 7, 9, 16, 17, 31, 33, 50, 64, 65, 100, 130]))
+        L = int(rng.choice([3, 5, 255, 256, 257, 258, 513, 768, 769, 770, 1537, 2304]))
+        alpha = ALPHABETS[int(rng.integers(0, 4))]
+        m = _random_matrix(rng, n, L, alpha, float(rng.choice([0.0, 0.002, 0.01, 0.03, 0.1, 0.3])))
+        mid = b.add_matrix(m)
+        b.add_unit(mid, cds=True)
+        units.append((m, None, True))
+        if n >= 3:
+            rows = rng.permutation(n)[: int(rng.integers(1, n + 1))].astype(np.uint32)
+            b.add_unit(mid, rows=rows, cds=True)
+            units.append((m, rows, True))
+    plan = scan.Plan(b.pack()[1])
+    assert 0 < plan.rows_per_chunk <= max(rows_per_chunk, 8)
+    plan.close()
+    out = scan.scan_batch(b, want_pos=True, want_sn=True)
+    for i, (m, rows, cds) in enumerate(units):
+        _compare(out, i, c_oracle.scan(m, rows=rows, cds=True, want_sites=True), True)
