@@ -781,6 +781,60 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
 }
 
 
+// Row-chunked coding scan, rare path (a column turns joint in a chunk after the first): the distinct
+// clean codons of the rows BEFORE the chunk, from the per-position alleles seen so far — the
+// consensus byte where the position did not vary yet, else the site's count slot as it stood before
+// the chunk (`list` / `cnt` at the given LDS byte offsets).  Returns ~0 when a position has no
+// usable counts (no slot, or a slot waiting for the column path).  Kept out of line so that its
+// scalar state does not weigh on the register allocation of the chunk loop.
+__device__ __attribute__((noinline)) unsigned long long codons_before_chunk(uint32_t list_off, uint32_t cnt_off, uint32_t P_prev,
+                                                                            uint32_t va_pre, uint32_t vd_pre, uint32_t rel,
+                                                                            uint32_t lane) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint32_t* const list = reinterpret_cast<const uint32_t*>(lds + list_off);
+  const uint32_t* const cnt = reinterpret_cast<const uint32_t*>(lds + cnt_off);
+  uint32_t pm[3] = {0u, 0u, 0u};             // presence masks over A, C, T, G (codon base order)
+  bool usable = true;
+#pragma unroll
+  for (uint32_t q = 0; q < 3u; ++q) {
+    const uint32_t sq = rel + q;
+    const uint32_t dbyte = ((uint32_t)__builtin_amdgcn_readlane((int)vd_pre, sq >> 2) >> (8u * (sq & 3u))) & 0xFFu;
+    const uint32_t abyte = ((uint32_t)__builtin_amdgcn_readlane((int)va_pre, sq >> 2) >> (8u * (sq & 3u))) & 0xFFu;
+    if (dbyte == 0u) {                       // every earlier row holds the consensus byte
+      pm[q] = base_clean(abyte) ? 1u << base_code(abyte) : 0u;
+    } else {                                 // the site's count slot, as it stood before this chunk
+      uint64_t hit = 0ull;
+      uint32_t base = 0u;
+      for (; base < P_prev && hit == 0ull; base += 64u)
+        hit = __ballot(base + lane < P_prev && (list[base + lane] >> 24) == sq);
+      if (hit == 0ull) { usable = false; continue; }
+      const uint32_t j = base - 64u + (uint32_t)__builtin_ctzll(hit);
+      const uint32_t ent = list[j];
+      const uint32_t mode = (ent >> 16) & 0xFFu;
+      const uint32_t* c6 = cnt + j * 6u;
+      if (mode == 0u) {
+        const uint32_t x = ent & 0xFFu, y = x ^ ((ent >> 8) & 0xFFu);
+        pm[q] = ((c6[0] != 0u && base_clean(x)) ? 1u << base_code(x) : 0u) |
+                ((c6[1] != 0u && base_clean(y)) ? 1u << base_code(y) : 0u);
+      } else if (mode == 1u) {               // counters A C G T - N
+        pm[q] = (c6[0] ? 1u : 0u) | (c6[1] ? 2u : 0u) | (c6[3] ? 4u : 0u) | (c6[2] ? 8u : 0u);
+      } else {
+        usable = false;
+      }
+    }
+  }
+  if (!usable) return ~0ull;
+  unsigned long long S = 0ull;
+#pragma unroll
+  for (uint32_t e0 = 0; e0 < 4u; ++e0)
+#pragma unroll
+    for (uint32_t e1 = 0; e1 < 4u; ++e1)
+#pragma unroll
+      for (uint32_t e2 = 0; e2 < 4u; ++e2)
+        if (((pm[0] >> e0) & (pm[1] >> e1) & (pm[2] >> e2) & 1u) != 0u) S |= 1ull << (16u * e0 + 4u * e1 + e2);
+  return S;
+}
+
 // ---------------------------------------------------------------- the tall kernel
 // Units with many rows (non-coding).  The classic kernel keeps all N rows of a 256-site tile in
 // LDS, so its occupancy falls as N grows (6 waves per CU at N = 100, 1 at N = 600).  Here a
@@ -1009,48 +1063,9 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
             const int end = __builtin_amdgcn_readlane(endoT[it], (uint32_t)__builtin_ctzll(m));
             const int rel = end - 2;
             if (rel < 0 || ncs >= CS) continue;          // read back at the end of the tile
-            // the distinct clean codons of the rows before this chunk: per position the alleles seen so far
-            unsigned long long S = 0ull;
-            bool usable = true;
-            if (r0 != 0u) {
-              uint32_t pm[3] = {0u, 0u, 0u};             // presence masks over A, C, T, G (codon base order)
-#pragma unroll
-              for (uint32_t q = 0; q < 3u; ++q) {
-                const uint32_t sq = (uint32_t)rel + q;
-                const uint32_t dbyte = ((uint32_t)__builtin_amdgcn_readlane((int)vd_pre, sq >> 2) >> (8u * (sq & 3u))) & 0xFFu;
-                const uint32_t abyte = ((uint32_t)__builtin_amdgcn_readlane((int)va_pre, sq >> 2) >> (8u * (sq & 3u))) & 0xFFu;
-                if (dbyte == 0u) {                       // every earlier row holds the consensus byte
-                  pm[q] = base_clean(abyte) ? 1u << base_code(abyte) : 0u;
-                } else {                                 // the site's count slot, as it stood before this chunk
-                  uint64_t hit = 0ull;
-                  uint32_t base = 0u;
-                  for (; base < P_prev && hit == 0ull; base += 64u)
-                    hit = __ballot(base + lane < P_prev && (list[base + lane] >> 24) == sq);
-                  if (hit == 0ull) { usable = false; continue; }
-                  const uint32_t j = base - 64u + (uint32_t)__builtin_ctzll(hit);
-                  const uint32_t ent = list[j];
-                  const uint32_t mode = (ent >> 16) & 0xFFu;
-                  const uint32_t* c6 = cnt + j * 6u;
-                  if (mode == 0u) {
-                    const uint32_t x = ent & 0xFFu, y = x ^ ((ent >> 8) & 0xFFu);
-                    pm[q] = ((c6[0] != 0u && base_clean(x)) ? 1u << base_code(x) : 0u) |
-                            ((c6[1] != 0u && base_clean(y)) ? 1u << base_code(y) : 0u);
-                  } else if (mode == 1u) {               // counters A C G T - N
-                    pm[q] = (c6[0] ? 1u : 0u) | (c6[1] ? 2u : 0u) | (c6[3] ? 4u : 0u) | (c6[2] ? 8u : 0u);
-                  } else {
-                    usable = false;
-                  }
-                }
-              }
-#pragma unroll
-              for (uint32_t e0 = 0; e0 < 4u; ++e0)
-#pragma unroll
-                for (uint32_t e1 = 0; e1 < 4u; ++e1)
-#pragma unroll
-                  for (uint32_t e2 = 0; e2 < 4u; ++e2)
-                    if (((pm[0] >> e0) & (pm[1] >> e1) & (pm[2] >> e2) & 1u) != 0u) S |= 1ull << (16u * e0 + 4u * e1 + e2);
-            }
-            if (!usable) continue;
+            // the distinct clean codons of the rows before this chunk
+            const unsigned long long S = r0 == 0u ? 0ull : codons_before_chunk(lo.list, lo.cnt, P_prev, va_pre, vd_pre, (uint32_t)rel, lane);
+            if (S == ~0ull) continue;                    // a position without usable counts: read back
             if (lane == 0u) { cs_end[ncs] = end; cs_set[ncs] = S; }
             ++ncs;
           }
