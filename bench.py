@@ -223,6 +223,20 @@ def main():
                       "gathered_records": None if gathered is None else int(len(gathered))},
         }
         line["roofline"]["traffic"] = measured_traffic(line["config"])
+        if world == 1 and not args.coding and not args.pops:
+            # BASELINE configs[1] literally: ONE alignment per launch (latency-bound: 500 KB of bases)
+            one = scan.Plan(scan.finalize_layout(descs[:1].copy(), None, nbytes))
+            for _ in range(20):
+                one.run(dev)
+            _lib.check(lib.pfa_sync())
+            t1 = time.perf_counter()
+            for _ in range(200):
+                one.run(dev)
+                one.fetch()
+            per = (time.perf_counter() - t1) / 200
+            line["single_alignment"] = {"us_per_scan_and_fetch": per * 1e6, "kernel_us": float(one.kernel_ms(50).mean()) * 1e3,
+                                        "note": "one N x L alignment per launch, bases resident, records fetched after every scan"}
+            one.close()
         if world == 1 and not args.no_cpu_baseline and not args.coding and not args.pops:
             cb, (s_cpu, h_cpu) = cpu_baseline(args, params)
             line["cpu_baseline"] = cb
