@@ -115,7 +115,6 @@ struct ScanArgs {
   uint32_t n_desc;
   uint32_t tiles_per_chunk;
   uint32_t n_max;
-  uint32_t pad;
   uint32_t use_rowmap; // 1 when some unit carries a row-index list
   uint32_t rows_per_chunk;  // tall kernel: rows staged per pass (multiple of 4, 8..64)
   uint32_t max_slots;       // tall kernel: count-table slots per tile (variable sites beyond take the column path)
@@ -1773,7 +1772,6 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   a.rows_per_chunk = p->rows_per_chunk;
   a.max_slots = p->max_slots;
   a.hist_bins = p->hist_bins;
-  a.pad = 0u;
 
   const int slot = (int)(p->n_runs % pfa::kEventRing);
   if (!p->ev0[slot]) PFA_HIP(hipEventCreate(&p->ev0[slot]));
