@@ -267,6 +267,15 @@ int64_t pfa_format_plain_rows(const char* prefix_blob, const uint64_t* prefix_of
                               const uint32_t* n_rows, const double* seqlen,
                               const double* a1, const double* e1, const double* e2, int jc,
                               char* out, uint64_t cap, int64_t* bad_row);
+/* The coding row (PolyFastA.py:151-180): "<name><sites_S>,<sites_N><mid>S_S,S_N,pi_S,pi_N,
+ * theta_S,theta_N,D_S,D_N,nstops\n", where name i = "file," and mid i = ",pop,N," are the caller's
+ * text, sites_S = sum_k syn_num[k] / (3 k) and sites_N = (seqlen - 3 missing_cols) - sites_S are
+ * printed through Python's round(x, 2), and the two polymorphism() tuples use them as their
+ * sequence lengths.  syn_num: PFA_SYN_BINS words per row.  Same return convention as above. */
+int64_t pfa_format_cds_rows(const char* name_blob, const uint64_t* name_off, const char* mid_blob, const uint64_t* mid_off,
+                            uint32_t n, const pfa_result* res, const uint32_t* syn_num, const uint32_t* n_rows,
+                            const uint32_t* seqlen, const double* a1, const double* e1, const double* e2, int jc,
+                            char* out, uint64_t cap, int64_t* bad_row);
 /* repr(float) of CPython 3 into out32 (at least 32 bytes, not NUL-terminated);
  * returns the length */
 int pfa_format_double(double x, char* out32);

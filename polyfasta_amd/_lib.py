@@ -106,6 +106,8 @@ _PROTOTYPES = {
                                               ctypes.c_uint32, _vp, ctypes.c_uint64]),
     "pfa_format_plain_rows": (ctypes.c_int64, [_vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
                                                _vp, ctypes.c_uint64, _vp]),
+    "pfa_format_cds_rows": (ctypes.c_int64, [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
+                                             _vp, ctypes.c_uint64, _vp]),
     "pfa_format_double": (ctypes.c_int, [ctypes.c_double, _vp]),
     "pfa_classify_codon_mask": (ctypes.c_uint32, [ctypes.c_uint64]),
     "pfa_classify_codon_masks_dev": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp]),

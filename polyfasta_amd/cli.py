@@ -386,6 +386,52 @@ def format_plain_rows_native(units, jc):
     return out[:got].tobytes().decode()
 
 
+def _blob(parts):
+    """(utf-8 bytes of the concatenation, uint64 offsets) of a list of strings"""
+    n = len(parts)
+    blob = "".join(parts).encode()
+    lens = np.fromiter(map(len, parts), dtype=np.uint64, count=n)
+    if int(lens.sum()) != len(blob):                       # non-ASCII text: lengths in bytes
+        lens = np.fromiter((len(x.encode()) for x in parts), dtype=np.uint64, count=n)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    return blob, off
+
+
+def _sample_size_constants(nrows):
+    uniq, inv = np.unique(nrows, return_inverse=True)
+    tab = np.array([((stats.harmonic_terms(int(k))[0],) + stats.tajima_e(int(k))) if k >= 2 else (0.0, 0.0, 0.0)
+                    for k in uniq], dtype=np.float64).reshape(-1, 3)
+    return tuple(np.ascontiguousarray(tab[inv, c]) for c in range(3))
+
+
+def format_cds_rows_native(units, jc):
+    """The coding rows of many units in one call (csrc/pfa_format.cpp).  `units`: sequences
+    (name, pop, n_rows, seqlen, record tuple, syn_num row).  Returns the text block, or None when
+    some row needs the Python path."""
+    import ctypes
+    from . import _lib
+    from ._lib import RESULT_DTYPE
+    n = len(units)
+    names, noff = _blob([f"{u[0]}," for u in units])
+    mids, moff = _blob([f",{u[1]},{u[2]}," for u in units])
+    rec = np.array([u[4] for u in units], dtype=RESULT_DTYPE)
+    syn = np.ascontiguousarray(np.stack([np.asarray(u[5], dtype=np.uint32) for u in units]))
+    nrows = np.fromiter((u[2] for u in units), dtype=np.uint32, count=n)
+    seqlen = np.fromiter((u[3] for u in units), dtype=np.uint32, count=n)
+    a1, e1, e2 = _sample_size_constants(nrows)
+    out = np.empty(len(names) + len(mids) + 320 * n + 16, dtype=np.uint8)
+    bad = ctypes.c_int64(-1)
+    got = _lib.load().pfa_format_cds_rows(names, _lib.ptr(noff), mids, _lib.ptr(moff), n, _lib.ptr(rec), _lib.ptr(syn),
+                                          _lib.ptr(nrows), _lib.ptr(seqlen), _lib.ptr(a1), _lib.ptr(e1), _lib.ptr(e2),
+                                          int(bool(jc)), _lib.ptr(out), len(out), ctypes.byref(bad))
+    if got < 0:
+        if bad.value >= 0:
+            return None
+        _lib.check(got)
+    return out[:got].tobytes().decode()
+
+
 NATIVE_ROWS_MIN = 64      # below this the per-row Python path is as fast
 
 
@@ -406,8 +452,11 @@ def emit(events, sink, cds, jc):
                 j += 1
             run = events[i:j]
             block = None
-            if not cds and len(run) >= NATIVE_ROWS_MIN and all(isinstance(e[5], int) for e in run):
-                block = format_plain_rows_native([(e[2], e[3], e[4], e[5], _fields(e[6])) for e in run], jc)
+            if len(run) >= NATIVE_ROWS_MIN and all(isinstance(e[5], int) and 0 <= e[5] < 2 ** 32 for e in run):
+                if not cds:
+                    block = format_plain_rows_native([(e[2], e[3], e[4], e[5], _fields(e[6])) for e in run], jc)
+                elif all(e[7] is not None for e in run):
+                    block = format_cds_rows_native([(e[2], e[3], e[4], e[5], _fields(e[6]), e[7]) for e in run], jc)
             if block is not None and sink.bulk_ok():
                 sink.rows(block)
             else:

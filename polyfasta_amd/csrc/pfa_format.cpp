@@ -13,6 +13,8 @@
 // formatted here: the call reports the first such row and the caller takes the Python path.
 #include <charconv>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/pfa.h"
@@ -96,6 +98,48 @@ int pfa_format_double(double x, char* out32) {
   return pfa::repr_double(x, out32);
 }
 
+// "S,pi,theta,D" of polymorphism() (PolyFastA.py:502-520) appended at out; returns the bytes
+// written, or -1 when the reference would raise (math domain error in Dvar, or seqlen == 0)
+static int put_polymorphism(unsigned long long S, unsigned long long H, uint32_t n_rows, double seqlen,
+                            double a1, double e1, double e2, int jc, char* out) {
+  if (S == 0) {                                            // PolyFastA.py:503-504, 436-437
+    memcpy(out, "0,0,0,NA", 8);
+    return 8;
+  }
+  if (n_rows < 2u || seqlen == 0.0) return -1;
+  const double ss = (double)S;
+  const double th_pi = (double)H / (double)((unsigned long long)n_rows * (n_rows - 1u));
+  const double th_wa = ss / a1;
+  const double rad = (e1 * ss) + (e2 * ss * (double)(S - 1ull));   // PolyFastA.py:534
+  if (!(rad >= 0.0)) return -1;                            // math.sqrt would raise
+  const double sd = std::sqrt(rad);
+  double pi_site = th_pi / seqlen;
+  if (jc) {                                                // PolyFastA.py:512-516 (bare except -> uncorrected value)
+    const double arg = 1.0 - (4.0 / 3.0) * pi_site;
+    if (arg > 0.0) pi_site = -0.75 * std::log(arg);
+  }
+  int w = pfa::put_u64(S, out);
+  out[w++] = ',';
+  w += pfa::repr_double(pi_site, out + w);
+  out[w++] = ',';
+  w += pfa::repr_double(th_wa / seqlen, out + w);
+  out[w++] = ',';
+  if (sd == 0.0) {                                         // ZeroDivisionError -> "NA" (PolyFastA.py:508-511)
+    out[w++] = 'N';
+    out[w++] = 'A';
+  } else {
+    w += pfa::repr_double((th_pi - th_wa) / sd, out + w);
+  }
+  return w;
+}
+
+// round(x, 2) of CPython: the correctly rounded two-decimal string, read back as a double
+static double py_round2(double x) {
+  char buf[400];
+  snprintf(buf, sizeof(buf), "%.2f", x);
+  return strtod(buf, nullptr);
+}
+
 int64_t pfa_format_plain_rows(const char* prefix_blob, const uint64_t* prefix_off, uint32_t n,
                               const uint32_t* seg_sites, const uint64_t* h_sum, const uint32_t* n_rows, const double* seqlen,
                               const double* a1, const double* e1, const double* e2, int jc,
@@ -111,40 +155,68 @@ int64_t pfa_format_plain_rows(const char* prefix_blob, const uint64_t* prefix_of
     if (w + plen + 128u > cap) { pfa::set_error("pfa_format_plain_rows: output capacity %llu too small", (unsigned long long)cap); return PFA_ERR_ARG; }
     memcpy(out + w, prefix_blob + prefix_off[i], plen);   // "file,seqlen,pop,N,"
     w += plen;
-    const unsigned long long S = seg_sites[i];
-    if (S == 0) {                                          // PolyFastA.py:503-504, 436-437
-      memcpy(out + w, "0,0,0,NA\n", 9);
-      w += 9;
-      continue;
-    }
-    const double ss = (double)S;
-    // polymorphism(), PolyFastA.py:505-520
-    const double th_pi = (double)h_sum[i] / (double)((unsigned long long)n_rows[i] * (n_rows[i] - 1u));
-    const double th_wa = ss / a1[i];
-    const double rad = (e1[i] * ss) + (e2[i] * ss * (double)(S - 1ull));   // PolyFastA.py:534
-    if (!(rad >= 0.0) || n_rows[i] < 2u) {   // math.sqrt would raise: the caller formats this batch in Python
+    const int k = put_polymorphism(seg_sites[i], h_sum[i], n_rows[i], seqlen[i], a1[i], e1[i], e2[i], jc, out + w);
+    if (k < 0) {   // the caller formats this batch in Python (and gets the reference's exception)
       if (bad_row) *bad_row = i;
-      pfa::set_error("pfa_format_plain_rows: row %u has no finite Tajima's D denominator", i);
+      pfa::set_error("pfa_format_plain_rows: row %u has no finite result", i);
       return PFA_ERR_ARG;
     }
-    const double sd = std::sqrt(rad);
-    double pi_site = th_pi / seqlen[i];
-    if (jc) {                                              // PolyFastA.py:512-516 (bare except -> uncorrected value)
-      const double arg = 1.0 - (4.0 / 3.0) * pi_site;
-      if (arg > 0.0) pi_site = -0.75 * std::log(arg);
+    w += (uint64_t)k;
+    out[w++] = '\n';
+  }
+  return (int64_t)w;
+}
+
+int64_t pfa_format_cds_rows(const char* name_blob, const uint64_t* name_off, const char* mid_blob, const uint64_t* mid_off,
+                            uint32_t n, const pfa_result* res, const uint32_t* syn_num, const uint32_t* n_rows,
+                            const uint32_t* seqlen, const double* a1, const double* e1, const double* e2, int jc,
+                            char* out, uint64_t cap, int64_t* bad_row) {
+  if (bad_row) *bad_row = -1;
+  if (n && (!name_blob || !name_off || !mid_blob || !mid_off || !res || !syn_num || !n_rows || !seqlen || !a1 || !e1 || !e2 || !out)) {
+    pfa::set_error("pfa_format_cds_rows: NULL argument");
+    return PFA_ERR_ARG;
+  }
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint64_t nlen = name_off[i + 1] - name_off[i], mlen = mid_off[i + 1] - mid_off[i];
+    if (w + nlen + mlen + 320u > cap) { pfa::set_error("pfa_format_cds_rows: output capacity %llu too small", (unsigned long long)cap); return PFA_ERR_ARG; }
+    // synonymous sites: sum over k of bin[k] / (3 k), ascending k (PolyFastA.py:307); the rest are non-synonymous (:154)
+    double ssites = 0.0;
+    const uint32_t* bins = syn_num + (uint64_t)i * PFA_SYN_BINS;
+    for (uint32_t k = 1; k < PFA_SYN_BINS; ++k)
+      if (bins[k]) ssites += (double)bins[k] / (3.0 * (double)k);
+    const double nsites = (double)((long long)seqlen[i] - 3ll * (long long)res[i].missing_cols) - ssites;
+    memcpy(out + w, name_blob + name_off[i], nlen);       // "file,"
+    w += nlen;
+    w += pfa::repr_double(py_round2(ssites), out + w);
+    out[w++] = ',';
+    w += pfa::repr_double(py_round2(nsites), out + w);
+    memcpy(out + w, mid_blob + mid_off[i], mlen);         // ",pop,N,"
+    w += mlen;
+    if (res[i].seg_sites == 0) {                           // PolyFastA.py:160-162 (the mis-ordered no-variation row)
+      memcpy(out + w, "0,0,0,NA,0,0,0,NA,0\n", 20);
+      w += 20;
+      continue;
     }
-    w += pfa::put_u64(S, out + w);
-    out[w++] = ',';
-    w += pfa::repr_double(pi_site, out + w);
-    out[w++] = ',';
-    w += pfa::repr_double(th_wa / seqlen[i], out + w);
-    out[w++] = ',';
-    if (sd == 0.0) {                                       // ZeroDivisionError -> "NA" (PolyFastA.py:508-511)
-      out[w++] = 'N';
-      out[w++] = 'A';
-    } else {
-      w += pfa::repr_double((th_pi - th_wa) / sd, out + w);
+    char ps[128], pn[128];
+    const int ks = put_polymorphism(res[i].seg_S, res[i].H_S, n_rows[i], ssites, a1[i], e1[i], e2[i], jc, ps);
+    const int kn = put_polymorphism(res[i].seg_N, res[i].H_N, n_rows[i], nsites, a1[i], e1[i], e2[i], jc, pn);
+    if (ks < 0 || kn < 0) {
+      if (bad_row) *bad_row = i;
+      pfa::set_error("pfa_format_cds_rows: row %u has no finite result", i);
+      return PFA_ERR_ARG;
     }
+    ps[ks] = pn[kn] = ',';   // sentinels: the fields of both tuples are interleaved (PolyFastA.py:176)
+    const char *a = ps, *b = pn;
+    for (int f = 0; f < 4; ++f) {
+      while (*a != ',') out[w++] = *a++;
+      ++a;
+      out[w++] = ',';
+      while (*b != ',') out[w++] = *b++;
+      ++b;
+      out[w++] = ',';
+    }
+    w += (uint64_t)pfa::put_u64(res[i].nstops, out + w);
     out[w++] = '\n';
   }
   return (int64_t)w;

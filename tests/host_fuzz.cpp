@@ -152,6 +152,36 @@ static void fuzz_rows() {
                                             a1.data(), e1.data(), e2.data(), (int)below(2), out, cap, &bad);
   if (got > (int64_t)cap) { fprintf(stderr, "format wrote %lld > cap %llu\n", (long long)got, (unsigned long long)cap); abort(); }
   free(out);
+  // coding rows on the same random table
+  {
+    std::vector<pfa_result> res(n);
+    std::vector<uint32_t> syn((size_t)n * PFA_SYN_BINS), sl(n);
+    std::vector<uint64_t> noff(n + 1, 0), moff(n + 1, 0);
+    std::string names, mids;
+    for (uint32_t i = 0; i < n; ++i) {
+      memset(&res[i], 0, sizeof(pfa_result));
+      res[i].seg_sites = seg[i];
+      res[i].seg_S = below(seg[i] + 1);
+      res[i].seg_N = below(seg[i] + 1);
+      res[i].H_S = h[i] >> 1;
+      res[i].H_N = h[i] >> 2;
+      res[i].nstops = below(50);
+      res[i].missing_cols = below(1000);
+      for (uint32_t k = 0; k < PFA_SYN_BINS; ++k) syn[(size_t)i * PFA_SYN_BINS + k] = below(4) ? 0 : below(100000);
+      sl[i] = below(20) ? below(100000) : 0;
+      names += "g" + std::to_string(i) + ",";
+      noff[i + 1] = names.size();
+      mids += ",NA," + std::to_string(nrows[i]) + ",";
+      moff[i + 1] = mids.size();
+    }
+    const uint64_t cap2 = below(4) ? names.size() + mids.size() + 320ull * n + 16 : below(400);
+    char* out2 = (char*)malloc(cap2 ? cap2 : 1);
+    int64_t bad2 = -1;
+    const int64_t got2 = pfa_format_cds_rows(names.data(), noff.data(), mids.data(), moff.data(), n, res.data(), syn.data(),
+                                             nrows.data(), sl.data(), a1.data(), e1.data(), e2.data(), (int)below(2), out2, cap2, &bad2);
+    if (got2 > (int64_t)cap2) { fprintf(stderr, "cds format wrote %lld > cap %llu\n", (long long)got2, (unsigned long long)cap2); abort(); }
+    free(out2);
+  }
   char buf[32];
   union { uint64_t u; double d; } x;
   x.u = rnd();

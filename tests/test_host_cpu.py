@@ -275,3 +275,44 @@ def test_emit_uses_native_rows_transparently(tmp_path, capsys):
     out2 = tmp_path / "o2.csv"
     cli.emit(events, cli.Sink(str(out2), False), False, False)      # progress chatter per row: row-by-row path
     assert out2.read_text() == "\n".join(want) + "\n"
+
+
+def test_native_cds_rows_match_python_rows():
+    """pfa_format_cds_rows == format_cds_row (PolyFastA.py:151-180): synonymous-site sums, Python's
+    round(x, 2), the two polymorphism() tuples interleaved, the mis-ordered no-variation row; rows on
+    which the reference raises (a sequence length of zero sites) send the batch to the Python path."""
+    rng = np.random.default_rng(31)
+    units, crashing = [], []
+    for i in range(6000):
+        n = int(rng.choice([2, 3, 4, 20, 50, 100, 300]))
+        L = int(rng.choice([3, 300, 9000, 9001, 100000]))
+        syn = np.zeros(_lib.PFA_SYN_BINS, dtype=np.uint32)
+        syn[1] = rng.integers(0, (L // 3) * 2 + 1)
+        for k in rng.integers(2, 6, 3):
+            syn[k] += rng.integers(0, 200)
+        if rng.random() < 0.03:
+            syn[:] = 0
+        seg = 0 if rng.random() < 0.1 else int(rng.integers(0, 400))
+        s_s = int(rng.integers(0, seg + 1)) if seg else 0
+        s_n = int(rng.integers(0, seg - s_s + 1)) if seg else 0
+        h_s, h_n = int(rng.integers(1, max(2, n * n // 2))) * s_s, int(rng.integers(1, max(2, n * n // 2))) * s_n
+        rec = (h_s + h_n, h_s, h_n, seg, 0, s_s, s_n, int(rng.integers(0, 30)), int(rng.integers(0, max(1, L // 30))), 0, 0)
+        u = (f"g{i}.fa", "NA" if i % 2 else "pop1", n, L, rec, syn)
+        try:
+            cli.format_cds_row(u[0], u[1], u[2], u[3], u[4], u[5], False)
+            units.append(u)
+        except (ZeroDivisionError, ValueError):
+            crashing.append(u)
+    assert len(units) > 5000 and crashing
+    for jc in (False, True):
+        want = "".join(cli.format_cds_row(u[0], u[1], u[2], u[3], u[4], u[5], jc) + "\n" for u in units)
+        assert cli.format_cds_rows_native(units, jc) == want
+    assert cli.format_cds_rows_native(units[:10] + crashing[:1], False) is None
+    # through emit: same file as the row-by-row path
+    events = [(i, "unit", u[0], u[1], u[2], u[3], u[4], u[5]) for i, u in enumerate(units[:500])]
+    import io
+    from contextlib import redirect_stdout
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        cli.emit(events, cli.Sink("", True), True, True)
+    assert buf.getvalue() == "".join(cli.format_cds_row(u[0], u[1], u[2], u[3], u[4], u[5], True) + "\n" for u in units[:500])
