@@ -854,7 +854,7 @@ __device__ inline uint32_t sym6(uint32_t x) {
   return x == 'A' ? 0u : x == 'C' ? 1u : x == 'G' ? 2u : x == 'T' ? 3u : x == '-' ? 4u : x == 'N' ? 5u : 6u;
 }
 
-template <int STAGE, bool HAS_CDS>
+template <int STAGE, bool HAS_CDS, bool LEAN>
 __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr uint32_t TW = 256u;
@@ -881,7 +881,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   const bool cds = HAS_CDS && (D.flags & PFA_FLAG_CDS) != 0u;
 
   const uint32_t nbins = N / 2u, HB = umin(nbins, A.hist_bins);
-  const bool mapped = D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
+  const bool mapped = !LEAN && D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
   const uint32_t* const ridx = A.row_idx + (mapped ? D.row_idx_off : 0u);
   const bool multi = N > R;
   for (uint32_t i = lane; i < HB; i += 64u) hist[i] = 0u;
@@ -897,7 +897,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   unsigned long long acc_H = 0ull;
   const uint8_t* const mat = A.bases + D.base_off;
   const unsigned long long NN = (unsigned long long)N * N;
-  CodonPass<false> cp;
+  CodonPass<LEAN> cp;
   if constexpr (HAS_CDS) cp.init(lane, synhist, A, D);
   auto hsite_get = [&](int rel) -> uint32_t { return hsite[rel]; };
   // H and which of A, C, T, G occur (codon base order) of a variable site, for the coding pass
@@ -1181,7 +1181,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     for (uint32_t b = 0; b < 4u; ++b) {
       const bool pb = ((vd >> (8u * b)) & 0xFFu) != 0u && 4u * lane + b < lim;
       const uint64_t m = __ballot(pb);
-      if (A.var_bm != nullptr && lane == 0u) A.var_bm[(uint64_t)(D.tile_off + tile) * 4u + b] = m;
+      if (!LEAN && A.var_bm != nullptr && lane == 0u) A.var_bm[(uint64_t)(D.tile_off + tile) * 4u + b] = m;
       acc_S += lane == 0u ? (uint32_t)__popcll(m) : 0u;
     }
     const uint32_t Pc = umin(P, MAXS);
@@ -1401,9 +1401,9 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
   return e && *e ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
 }
 
-template <int STAGE, bool CDS>
+template <int STAGE, bool CDS, bool LEAN>
 static int launch_tall(const pfa_plan* p, const ScanArgs& a) {
-  auto kern = scan_tall_kernel<STAGE, CDS>;
+  auto kern = scan_tall_kernel<STAGE, CDS, LEAN>;
   static uint32_t lds_limit_set = 0;
   if (p->lds_bytes > lds_limit_set) {
     PFA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1784,12 +1784,14 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   (stage == 0 ? pfa::launch<0, CDS, LEAN>(p, a)                        \
               : stage == 1 ? pfa::launch<1, CDS, LEAN>(p, a) : pfa::launch<2, CDS, LEAN>(p, a))
   const bool lean = !p->use_rowmap && !p->d_var_bm && !p->d_syn_bm;
-  if (p->tall && p->any_cds)
-    rc = stage == 0 ? pfa::launch_tall<0, true>(p, a) : stage == 1 ? pfa::launch_tall<1, true>(p, a) : pfa::launch_tall<2, true>(p, a);
-  else if (p->tall)
-    rc = stage == 0 ? pfa::launch_tall<0, false>(p, a) : stage == 1 ? pfa::launch_tall<1, false>(p, a) : pfa::launch_tall<2, false>(p, a);
+#define PFA_LAUNCH_TALL(CDS, LEAN)                                     \
+  (stage == 0 ? pfa::launch_tall<0, CDS, LEAN>(p, a)                   \
+              : stage == 1 ? pfa::launch_tall<1, CDS, LEAN>(p, a) : pfa::launch_tall<2, CDS, LEAN>(p, a))
+  if (p->tall && lean) rc = p->any_cds ? PFA_LAUNCH_TALL(true, true) : PFA_LAUNCH_TALL(false, true);
+  else if (p->tall)    rc = p->any_cds ? PFA_LAUNCH_TALL(true, false) : PFA_LAUNCH_TALL(false, false);
   else if (lean) rc = p->any_cds ? PFA_LAUNCH(true, true) : PFA_LAUNCH(false, true);
   else           rc = p->any_cds ? PFA_LAUNCH(true, false) : PFA_LAUNCH(false, false);
+#undef PFA_LAUNCH_TALL
 #undef PFA_LAUNCH
   if (rc != PFA_OK) return rc;
   PFA_HIP(hipEventRecord(p->ev1[slot], st));
