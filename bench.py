@@ -242,7 +242,7 @@ def main():
                       "gathered_records": None if gathered is None else int(len(gathered))},
         }
         line["roofline"]["traffic"] = measured_traffic(line["config"])
-        if world == 1 and not args.coding and not args.pops:
+        if world == 1 and not args.coding and not args.pops and not args.no_cpu_baseline:   # (not under the profiler)
             # BASELINE configs[1] literally: ONE alignment per launch (latency-bound: 500 KB of bases)
             one = scan.Plan(scan.finalize_layout(descs[:1].copy(), None, nbytes))
             for _ in range(20):
