@@ -17,12 +17,12 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)   # newest run
 shutil.copyfile(stats, os.path.join(dst, f"{name}_kernel_stats.csv"))
 
 
 def counter(kind, cname):
-    f = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
             if r["Counter_Name"] == cname and "pfa::scan_" in r["Kernel_Name"]]
     return vals
