@@ -206,3 +206,32 @@ def test_tall_kernel_coding_forced_on_small_units(gpu, monkeypatch, rows_per_chu
     out = scan.scan_batch(b, want_pos=True, want_sn=True)
     for i, (m, rows, cds) in enumerate(units):
         _compare(out, i, c_oracle.scan(m, rows=rows, cds=True, want_sites=True), True)
+
+
+@pytest.mark.parametrize("seed,cds", [(0, False), (1, True), (2, True)])
+def test_random_many_row_batches_lean_kernels(gpu, seed, cds):
+    """Many-row plans without row subsets and bitmaps: the lean instantiations of the row-chunked
+    kernel (what `--dir` batches of large alignments run), coding and not."""
+    rng = np.random.default_rng(4242 + seed)
+    b = scan.Batch(stride_align=[128, 16, 64][seed])
+    units = []
+    for _ in range(30):
+        n = int(rng.choice([65, 100, 128, 129, 200, 255, 300, 700]))
+        L = int(rng.choice([3, 255, 256, 257, 770, 1537, 3001]))
+        m = _random_matrix(rng, n, L, ALPHABETS[int(rng.integers(0, 4))], float(rng.choice([0.0, 0.002, 0.01, 0.05])))
+        b.add_unit(b.add_matrix(m), cds=cds)
+        units.append(m)
+    plan = scan.Plan(b.pack()[1])
+    assert plan.rows_per_chunk > 0
+    plan.close()
+    out = scan.scan_batch(b)
+    from polyfasta_amd import stats
+    for i, m in enumerate(units):
+        o = c_oracle.scan(m, cds=cds)
+        r = out.results[i]
+        assert (int(r["seg_sites"]), int(r["H"]), int(r["sfs_bad"])) == (o["S"], o["H"], o["sfs_bad"]), (i, m.shape)
+        assert out.sfs(i).tolist() == o["sfs"].tolist()
+        if cds:
+            assert (int(r["seg_S"]), int(r["seg_N"]), int(r["H_S"]), int(r["H_N"]), int(r["nstops"]), int(r["missing_cols"])) == \
+                   (o["seg_S"], o["seg_N"], o["H_S"], o["H_N"], o["nstops"], o["missing_cols"]), (i, m.shape)
+            assert abs(stats.syn_sites_from_bins(out.syn_num[i]) - o["count_syn"]) <= 1e-9 * max(1.0, o["count_syn"])
