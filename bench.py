@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py — the polymorphism-scan hot path on N GPUs of one node.
 
-A *step* is one pass of the scan kernel over one device-resident batch of
-synthetic alignments (BASELINE.json configs[1] shape: N=50 sequences x L=10 kb,
-theta = 0.01, non-coding; `--batch` of them per GPU, distinct, generated on the
-device by the deterministic generator, so the working set is several times the
-256 MiB Infinity Cache).  Multi-GPU = the reference's `--dir` batch mode:
-independent alignments sharded over ranks (weak scaling: every rank scans its
-own `--batch` alignments per step), no collective on the data path, ONE RCCL
-all-gather of the fixed-size result records at the end, inside the timed region.
+A *step* is one pass of the scan kernel over one device-resident batch of synthetic
+alignments (BASELINE.json configs[1] shape: N=50 sequences x L=10 kb, theta = 0.01,
+non-coding; `--batch` of them per GPU, distinct, generated on the device by the
+deterministic generator, so the working set is many times the 256 MiB Infinity Cache).
+Multi-GPU = the reference's `--dir` batch mode: independent alignments sharded over ranks
+(weak scaling: every rank scans its own `--batch` alignments per step), no collective on
+the data path, ONE RCCL all-gather of the fixed-size result records at the end, inside the
+timed region (pfa_comm_* of the C ABI: no torch anywhere).
 
-Prints one JSON line on rank 0 (contract in the task statement) carrying
-`roofline` (algorithmic bytes = N*L per alignment, kernel time from HIP events
-recorded on the launch stream) and `cpu_baseline` (the C oracle, one core, on a
-bounded sample of the same workload; N=1 only).
+`--gpus N` without a launcher's WORLD_SIZE starts the N ranks itself (one process per GPU,
+before anything here touches the GPU) and fails loudly when fewer GPUs are visible; under
+`python -m torch.distributed.run` the ranks are read from RANK / LOCAL_RANK / WORLD_SIZE.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline`
+(algorithmic bytes = N*L per alignment, kernel time from HIP events on the launch stream),
+and at N=1 also `cpu_baseline` (the C oracle and the pure-Python restatement on the host
+cores, bounded samples), `workloads` (the other BASELINE shapes, device-resident, each with
+its own roofline fraction), `single_alignment` / `config3_one_launch` (latency of small
+launches) and `end_to_end` (FASTA files in tmpfs -> CSV rows through the CLI).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -30,7 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -40,198 +47,347 @@ def parse():
     ap.add_argument("--sites", type=int, default=10000)
     ap.add_argument("--theta", type=float, default=0.01)
     ap.add_argument("--stride-align", type=int, default=128)
-    ap.add_argument("--variant", type=int, default=0, help="0 = LDS-DMA nt (default), 1 = register staging, 2 = LDS-DMA default cache policy")
+    ap.add_argument("--variant", type=int, default=0, help="0 = LDS-DMA nt (default), 2 = LDS-DMA default cache policy")
     ap.add_argument("--coding", action="store_true", help="scan as in-frame CDS (config 4 shape with --sites 9000)")
     ap.add_argument("--pops", type=int, default=0,
                     help="config 3 shape: every matrix holds rows*pops sequences, scanned as `pops` interleaved row subsets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="headline measurement only (profiling runs)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--e2e-files", type=int, default=2048)
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(args, params):
-    """Time the C oracle (scalar, one core) on a bounded sample of the workload."""
-    from oracle import c_oracle
+# ------------------------------------------------------------------ workloads
+class Workload:
+    """A device-resident batch of synthetic alignments and its scan plan."""
+
+    def __init__(self, rows, sites, batch, theta=0.01, coding=False, pops=0, stride_align=128, first_aln=0, timing=True):
+        from polyfasta_amd import _lib, scan, synth
+        lib = _lib.load()
+        self.N, self.L, self.B, self.K = rows, sites, batch, max(pops, 1)
+        self.coding, self.pops = coding, pops
+        NM = rows * self.K
+        self.params = synth.make_params(NM, theta)
+        self.stride = scan.row_stride_for(sites, stride_align)
+        self.nbytes = batch * NM * self.stride
+        self.dev = scan.DeviceBuffer(self.nbytes)
+        sp = _lib.SynthParamsC(seed=2026, first_aln=first_aln, n_aln=batch, n_rows=NM, n_sites=sites, row_stride=self.stride,
+                               seg_thresh=self.params.seg_thresh, tri_thresh=self.params.tri_thresh,
+                               n_units=len(self.params.units), coding=int(coding))
+        _lib.check(lib.pfa_synth_fill_dev(self.dev.ptr, ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(self.params.cdf)),
+                                          _lib.ptr(np.ascontiguousarray(self.params.units))))
+        descs = np.zeros(batch * self.K, dtype=_lib.DESC_DTYPE)
+        descs["base_off"] = np.repeat(np.arange(batch, dtype=np.uint64) * np.uint64(NM * self.stride), self.K)
+        descs["n_rows"], descs["n_sites"], descs["row_stride"], descs["mat_rows"] = rows, sites, self.stride, NM
+        descs["row_idx_off"] = _lib.PFA_NO_ROW_IDX
+        descs["flags"] = _lib.PFA_FLAG_CDS if coding else 0
+        row_idx = None
+        if pops:                                 # population k = rows k, k+K, k+2K, ... (headers pop{1+i%K}_ind{i})
+            row_idx = np.concatenate([np.arange(k, NM, self.K, dtype=np.uint32) for k in range(self.K)])
+            descs["row_idx_off"] = np.tile(np.arange(self.K, dtype=np.uint32) * rows, batch)
+        self.descs, self.row_idx = descs, row_idx
+        self.table = scan.finalize_layout(descs, row_idx, self.nbytes)
+        self.plan = scan.Plan(self.table, timing=timing)
+        self.alg_bytes = float(batch) * NM * sites      # every base of every population is read once
+
+    def label(self):
+        s = f"{self.B} distinct alignments, N={self.N} x L={self.L}, {'coding (--cds)' if self.coding else 'non-coding'}"
+        if self.pops:
+            s += f", {self.K} populations of {self.N} rows per {self.N * self.K}-row matrix (--pops)"
+        return s
+
+    def measure(self, steps, warmup, variant=0):
+        """kernel-only figures from HIP events around the launches of `steps` runs"""
+        from polyfasta_amd import _lib
+        for _ in range(warmup):
+            self.plan.run(self.dev, variant=variant)
+        for _ in range(steps):
+            self.plan.run(self.dev, variant=variant)
+        _lib.check(_lib.load().pfa_sync())
+        kms = self.plan.kernel_ms(steps)
+        avg = float(kms.mean())
+        ach = self.alg_bytes / (avg * 1e-3) / 1e9
+        return {"workload": self.label(), "kernel": self.plan.description, "launches_per_run": self.plan.n_launches,
+                "kernel_ms_avg": avg, "kernel_ms_min": float(kms.min()), "algorithmic_bytes_per_launch": self.alg_bytes,
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+
+    def close(self):
+        self.plan.close()
+        self.dev.free()
+
+
+def extra_workloads(args):
+    """The other BASELINE shapes as short device-resident passes (kernel time from HIP events)."""
+    out = {}
+    for key, kw in (("C4_coding_50x9000", dict(rows=50, sites=9000, batch=32768, coding=True)),
+                    ("C3_pops_2x100x100000", dict(rows=100, sites=100000, batch=128, pops=2)),
+                    ("N200_plain_200x100000", dict(rows=200, sites=100000, batch=128)),
+                    ("N200_coding_200x9000", dict(rows=200, sites=9000, batch=8192, coding=True))):
+        w = Workload(theta=args.theta, stride_align=args.stride_align, **kw)
+        out[key] = w.measure(steps=12, warmup=3)
+        o = w.plan.fetch()
+        out[key]["check"] = {"mean_seg_sites": float(o.results["seg_sites"].mean()), "sum_H": int(o.results["H"].sum())}
+        w.close()
+    return out
+
+
+def small_launches(hw, args):
+    """BASELINE configs[1] and [2] literally: ONE alignment per launch (latency-bound: 500 KB of
+    bases), and config 3 (200 x 100 kb, two populations) as one launch of two units."""
     from polyfasta_amd import _lib, scan
+    lib = _lib.load()
+    rep = {}
+    one = scan.Plan(scan.finalize_layout(hw.descs[:1].copy(), None, hw.nbytes))
+    for _ in range(20):
+        one.run(hw.dev)
+        one.fetch()
+    t1 = time.perf_counter()
+    for _ in range(500):
+        one.run(hw.dev)
+        one.fetch()
+    per = (time.perf_counter() - t1) / 500
+    _lib.check(lib.pfa_plan_set_timing(one.handle, 1))     # HIP events around the launch: kernel time alone
+    for _ in range(60):
+        one.run(hw.dev)
+        one.fetch()
+    k = one.kernel_ms(50)
+    rep["single_alignment"] = {"us_per_scan_and_fetch": per * 1e6, "kernel_us": float(k.mean()) * 1e3, "kernel_us_min": float(k.min()) * 1e3,
+                               "plan": one.description,
+                               "note": "one N x L alignment per launch, bases resident, records fetched after every scan"}
+    one.close()
+    c3 = Workload(rows=100, sites=100000, batch=1, pops=2, theta=args.theta, stride_align=args.stride_align)
+    for _ in range(20):
+        c3.plan.run(c3.dev)
+        c3.plan.fetch()
+    k = c3.plan.kernel_ms(16)
+    rep["config3_one_launch"] = {"kernel_us": float(k.mean()) * 1e3, "kernel_us_min": float(k.min()) * 1e3,
+                                 "bytes": c3.alg_bytes, "achieved_GBps": c3.alg_bytes / (float(k.mean()) * 1e-3) / 1e9,
+                                 "plan": c3.plan.description,
+                                 "note": "BASELINE configs[2] literally: one 200 x 100 kb matrix, two 100-row populations, one launch"}
+    c3.close()
+    return rep
+
+
+def end_to_end(args):
+    """FASTA files in tmpfs -> CSV rows through the CLI (`-d DIR -o out.csv -s`), rows checked against the C oracle."""
+    import io
+    import shutil
+    import tempfile
+    from contextlib import redirect_stdout
+    from oracle import c_oracle
+    from polyfasta_amd import _lib, cli, scan, synth
+    lib = _lib.load()
+    N, L, M = 50, 10000, args.e2e_files
+    p = synth.make_params(N, args.theta)
+    stride = scan.row_stride_for(L, 128)
+    sp = _lib.SynthParamsC(seed=7, first_aln=0, n_aln=M, n_rows=N, n_sites=L, row_stride=stride,
+                           seg_thresh=p.seg_thresh, tri_thresh=p.tri_thresh, n_units=len(p.units), coding=0)
+    bases = np.zeros(M * N * stride, dtype=np.uint8)
+    _lib.check(lib.pfa_synth_fill_host(_lib.ptr(bases), ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(p.cdf)),
+                                       _lib.ptr(np.ascontiguousarray(p.units))))
+    d = tempfile.mkdtemp(prefix="pfa_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        hdr = [f">indiv{i + 1}\n".encode() for i in range(N)]
+        t0 = time.perf_counter()
+        for m in range(M):
+            mat = bases[m * N * stride:(m + 1) * N * stride].reshape(N, stride)[:, :L]
+            with open(os.path.join(d, f"aln{m:06d}.fa"), "wb") as fh:
+                fh.write(b"".join(h + mat[i].tobytes() + b"\n" for i, h in enumerate(hdr)))
+        t_write = time.perf_counter() - t0
+        out = os.path.join(tempfile.gettempdir(), f"pfa_e2e_out_{os.getpid()}.csv")
+        best = None
+        for rep in range(3):
+            if os.path.exists(out):
+                os.unlink(out)
+            buf = io.StringIO()
+            t0 = time.perf_counter()
+            with redirect_stdout(buf):
+                rc = cli.main(["-d", d, "-o", out, "-s"])
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        rows = open(out).read().splitlines()
+        os.unlink(out)
+        s_cpu, h_cpu = c_oracle.scan_many(bases, 64, N, L, stride)        # the first 64 files against the oracle
+        ok = rc == 0 and len(rows) == M and [r.split(",")[0] for r in rows] == [f"aln{m:06d}.fa" for m in range(M)]
+        for i in range(64):
+            f = rows[i].split(",")
+            pi = float(f[5])
+            ok = ok and int(f[4]) == int(s_cpu[i]) and abs(pi - int(h_cpu[i]) / (N * (N - 1)) / L) <= 1e-12 * pi
+        return {"alignments_per_s": M / best, "seconds": best, "files": M, "text_GBps": M * N * (L + 10) / best / 1e9,
+                "rows_ok": bool(ok), "write_files_s": t_write, "loader_threads": int(os.environ.get("PFA_THREADS", "0")) or min(16, os.cpu_count() or 1),
+                "command": "python -m polyfasta_amd -d DIR -o out.csv -s (in-process, page-cached files in tmpfs, best of 3)",
+                "target_alignments_per_s": 10000}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def cpu_baseline(args, hw):
+    """The CPU restatements timed beside the GPU (reported baselines, never targets):
+    the C oracle on 1 core and on all host cores, the pure-Python oracle (the reference's own loop
+    structure) on 1 core; bounded samples of the headline workload."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import c_oracle, polyfasta_oracle
+    from polyfasta_amd import _lib, synth
     n_mat = 128
-    stride = scan.row_stride_for(args.sites, args.stride_align)
-    sp = _lib.SynthParamsC(seed=2026, first_aln=0, n_aln=n_mat, n_rows=args.rows, n_sites=args.sites,
-                           row_stride=stride, seg_thresh=params.seg_thresh, tri_thresh=params.tri_thresh,
-                           n_units=len(params.units), coding=0)
-    bases = np.zeros(n_mat * args.rows * stride, dtype=np.uint8)
-    _lib.check(_lib.load().pfa_synth_fill_host(_lib.ptr(bases), ctypes.byref(sp),
-                                               _lib.ptr(np.ascontiguousarray(params.cdf)),
-                                               _lib.ptr(np.ascontiguousarray(params.units))))
-    c_oracle.scan_many(bases, 4, args.rows, args.sites, stride)  # warm
+    N, L, stride = hw.N, hw.L, hw.stride
+    sp = _lib.SynthParamsC(seed=2026, first_aln=0, n_aln=n_mat, n_rows=N, n_sites=L, row_stride=stride,
+                           seg_thresh=hw.params.seg_thresh, tri_thresh=hw.params.tri_thresh, n_units=len(hw.params.units), coding=0)
+    bases = np.zeros(n_mat * N * stride, dtype=np.uint8)
+    _lib.check(_lib.load().pfa_synth_fill_host(_lib.ptr(bases), ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(hw.params.cdf)),
+                                               _lib.ptr(np.ascontiguousarray(hw.params.units))))
+    c_oracle.scan_many(bases, 4, N, L, stride)  # warm
     done, t0 = 0, time.perf_counter()
     while True:
-        s, h = c_oracle.scan_many(bases, n_mat, args.rows, args.sites, stride)
+        s, h = c_oracle.scan_many(bases, n_mat, N, L, stride)
         done += n_mat
         dt = time.perf_counter() - t0
         if dt >= args.cpu_seconds:
             break
-    # the same scalar code on several host threads at once (ctypes releases the GIL): the GPU box
-    # gives one GPU's share of the host, 16 cores
-    from concurrent.futures import ThreadPoolExecutor
-    T = max(1, min(16, os.cpu_count() or 1))
-    per = n_mat // T if n_mat >= T else 1
-    slices = [bases[k * per * args.rows * stride:(k + 1) * per * args.rows * stride] for k in range(min(T, n_mat))]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    T = max(1, cores)
+    per = max(1, n_mat // T)
+    slices = [bases[(k % (n_mat // per)) * per * N * stride:((k % (n_mat // per)) + 1) * per * N * stride] for k in range(T)]
 
-    def worker(sl):
+    def worker(sl):     # the same scalar code on every host core at once (ctypes releases the GIL)
         n, t_end = 0, time.perf_counter() + min(args.cpu_seconds, 5.0)
         while time.perf_counter() < t_end:
-            c_oracle.scan_many(sl, per, args.rows, args.sites, stride)
+            c_oracle.scan_many(sl, per, N, L, stride)
             n += per
         return n
     tm = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=len(slices)) as ex:
+    with ThreadPoolExecutor(max_workers=T) as ex:
         done_mt = sum(ex.map(worker, slices))
     dt_mt = time.perf_counter() - tm
-    multi = {"value": done_mt / dt_mt, "unit": "alignments/s", "cores": len(slices), "kind": "port",
-             "sample": f"the same scalar scan on {len(slices)} host threads for {dt_mt:.1f} s"}
-    return {"value": done / dt, "unit": "alignments/s", "cores": 1, "kind": "port", "multi_thread": multi,
-            "sample": f"{n_mat} distinct synthetic alignments ({args.rows}x{args.sites}, same generator) scanned "
-                      f"repeatedly by oracle/pfa_oracle.c for {dt:.1f} s on 1 of {os.cpu_count()} host cores",
-            "host_cores": os.cpu_count()}, (s, h)
+    # the pure-Python restatement: the reference's per-site loop structure (getvarsites + polymorphism)
+    d = synth.to_dict(synth.headers_for(N), bases[:N * stride].reshape(N, stride)[:, :L])
+    n_py, tp = 0, time.perf_counter()
+    while True:
+        pos, var = polyfasta_oracle.getvarsites(d, L)
+        poly = polyfasta_oracle.polymorphism(var, L, False)
+        n_py += 1
+        dt_py = time.perf_counter() - tp
+        if dt_py >= min(args.cpu_seconds, 5.0):
+            break
+    return {"value": done / dt, "unit": "alignments/s", "cores": 1, "kind": "port",
+            "sample": f"{n_mat} distinct synthetic alignments ({N}x{L}, same generator) scanned repeatedly by "
+                      f"oracle/pfa_oracle.c for {dt:.1f} s on 1 of {os.cpu_count()} host cores",
+            "host_cores": os.cpu_count(),
+            "all_cores": {"value": done_mt / dt_mt, "unit": "alignments/s", "cores": T, "kind": "port",
+                          "sample": f"the same scalar C scan on {T} host threads (every core this process may use) for {dt_mt:.1f} s"},
+            "pure_python": {"value": n_py / dt_py, "unit": "alignments/s", "cores": 1, "kind": "port",
+                            "sample": f"oracle/polyfasta_oracle.py (the reference's loop structure: getvarsites + polymorphism) on "
+                                      f"{n_py} alignment(s) of the same workload for {dt_py:.1f} s; S = {poly[0]} = the GPU's: "
+                                      f"{poly[0] == int(s[0])}"}}, (s, h)
 
 
 def measured_traffic(cfg):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of this exact
-    workload (profiles/*_pmc_summary.json, made by tools/gpu_prof.sh +
-    tools/summarize_prof.py: separate --pmc passes, gfx950 correction), or None."""
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this exact workload
+    (profiles/*_pmc_summary.json, made by tools/gpu_prof.sh + tools/summarize_prof.py: separate
+    --pmc passes, gfx950 correction).  Returns (bytes or None, where the figure comes from): the
+    value is only reported when the summary was taken with the kernel sources as they are now."""
     import glob
-    best = None
+    src_sha = kernel_sources_sha()
+    best, source = None, {"note": "no committed PMC summary matches this workload"}
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
         try:
             j = json.load(open(f))
         except Exception:
             continue
         w = j.get("workload", {})
-        if all(w.get(k) == cfg.get(k) for k in ("rows", "sites", "batch_per_gpu", "row_stride", "kernel_variant")) \
+        if all(w.get(k) == cfg.get(k) for k in ("rows", "sites", "batch_per_gpu", "row_stride")) \
                 and all((k in w.get("workload", "")) == (k in cfg.get("workload", "")) for k in ("coding", "populations")):
-            best = j.get("traffic_bytes_per_launch")
-    return best
+            fresh = j.get("kernel_sources_sha16") == src_sha
+            source = {"file": os.path.relpath(f, ROOT), "kernel_sources_sha16": j.get("kernel_sources_sha16"),
+                      "current_kernel_sources_sha16": src_sha, "fresh": fresh, "collected": j.get("collected"),
+                      "method": "separate rocprofv3 --pmc passes; HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950, MI355X_MICROARCH.md §HBM)"}
+            best = j.get("traffic_bytes_per_launch") if fresh else None
+    return best, source
+
+
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    for f in ("pfa_kernels.h", "pfa_layout.h", "pfa_codon.h", "pfa_scan_classic.hip", "pfa_scan_tall.hip", "pfa_plan.hip"):
+        h.update(open(os.path.join(ROOT, "polyfasta_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    from polyfasta_amd import dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU, started before this process touches the GPU; non-zero when GPUs are missing
+        sys.exit(dist.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    rank, local_rank, world = dist.env_world()
+    if world > 1:
         args.gpus = world
 
-    dist = None
-    if world > 1 or os.environ.get("PFA_FORCE_DIST"):   # PFA_FORCE_DIST: rehearse the RCCL path on one GPU
-        import torch
-        import torch.distributed as dist
-        from polyfasta_amd.dist import stdout_to_stderr
-        with stdout_to_stderr():         # RCCL's version banner must not join the one JSON line on stdout
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            dist.barrier()
-            torch.cuda.synchronize()
-    from polyfasta_amd import _lib, scan, synth
-
+    from polyfasta_amd import _lib
     lib = _lib.load()
-    _lib.init(local_rank)
+    _lib.init()                                   # GPU LOCAL_RANK; fails loudly when it is not there
+    comm = dist.RcclComm() if (world > 1 or os.environ.get("PFA_FORCE_DIST")) else None   # PFA_FORCE_DIST: 1-rank RCCL rehearsal
 
-    N, L, B = args.rows, args.sites, args.batch
-    K = max(args.pops, 1)
-    NM = N * K                               # rows of each matrix
-    params = synth.make_params(NM, args.theta)
-    stride = scan.row_stride_for(L, args.stride_align)
-    nbytes = B * NM * stride
-    dev = scan.DeviceBuffer(nbytes)
-    sp = _lib.SynthParamsC(seed=2026, first_aln=rank * B, n_aln=B, n_rows=NM, n_sites=L, row_stride=stride,
-                           seg_thresh=params.seg_thresh, tri_thresh=params.tri_thresh, n_units=len(params.units),
-                           coding=int(args.coding))
-    _lib.check(lib.pfa_synth_fill_dev(dev.ptr, ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(params.cdf)),
-                                      _lib.ptr(np.ascontiguousarray(params.units))))
-    descs = np.zeros(B * K, dtype=_lib.DESC_DTYPE)
-    descs["base_off"] = np.repeat(np.arange(B, dtype=np.uint64) * np.uint64(NM * stride), K)
-    descs["n_rows"], descs["n_sites"], descs["row_stride"], descs["mat_rows"] = N, L, stride, NM
-    descs["row_idx_off"] = _lib.PFA_NO_ROW_IDX
-    descs["flags"] = _lib.PFA_FLAG_CDS if args.coding else 0
-    if os.environ.get("PFA_BENCH_MIX_ONE_CDS"):   # experiment: coding-capable kernel on non-coding units
-        descs["flags"][0] = _lib.PFA_FLAG_CDS
-    row_idx = None
-    if args.pops:                            # population k = rows k, k+K, k+2K, ... (headers pop{1+i%K}_ind{i})
-        row_idx = np.concatenate([np.arange(k, NM, K, dtype=np.uint32) for k in range(K)])
-        descs["row_idx_off"] = np.tile(np.arange(K, dtype=np.uint32) * N, B)
-    table = scan.finalize_layout(descs, row_idx, nbytes)
-    plan = scan.Plan(table)
+    hw = Workload(args.rows, args.sites, args.batch, theta=args.theta, coding=args.coding, pops=args.pops,
+                  stride_align=args.stride_align, first_aln=rank * args.batch)
+    plan, dev = hw.plan, hw.dev
 
     def sync_all():
         _lib.check(lib.pfa_sync())
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def gather_records(out):
-        """the only collective of the job: the fixed-size result records of every rank, to every rank"""
-        import torch
-        local = torch.from_numpy(out.results.view(np.uint8).reshape(-1).copy()).cuda()
-        allr = torch.empty(world * local.numel(), dtype=torch.uint8, device="cuda")
-        dist.all_gather_into_tensor(allr, local)
-        torch.cuda.synchronize()
-        return allr.cpu().numpy().view(_lib.RESULT_DTYPE)
+        if comm is not None:
+            comm.barrier()
+            _lib.check(lib.pfa_sync())
 
     for w in range(args.warmup):
         plan.run(dev, variant=args.variant)
-        out = plan.fetch()
-        if dist is not None and w == 0:
-            gather_records(out)              # RCCL sets up its channels on the first collective of a shape
+        if comm is not None and w == 0:
+            comm.all_gather_plan_results(plan)   # RCCL sets up its channels on the first collective of a shape
+        plan.fetch()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         plan.run(dev, variant=args.variant)
     t_enq = time.perf_counter() - t0
+    gathered = None
+    if comm is not None:
+        # the only collective of the job: the fixed-size result records of every rank, to every rank,
+        # straight from device memory behind the last scan on the same stream
+        gathered = comm.all_gather_plan_results(plan)
     _lib.check(lib.pfa_sync())
     t_run = time.perf_counter() - t0
     out = plan.fetch()                       # D2H of the integer records (part of the job)
     t_fetch = time.perf_counter() - t0 - t_run
-    gathered = None
-    if dist is not None:
-        gathered = gather_records(out)
     sync_all()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    if comm is not None:
+        dt = comm.max_float(dt)
 
     kms = plan.kernel_ms(args.steps)
     k_avg_ms = float(kms.mean()) if len(kms) else float("nan")
-    alg_bytes = float(B) * NM * L           # every base of every population is read once
-    achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+    achieved = hw.alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
 
     if rank == 0:
         res = out.results
+        N, L, B, K = hw.N, hw.L, hw.B, hw.K
         total_aln = world * B * K * args.steps   # scan units (alignment x population) = CSV rows
+        default_shape = (N, L, args.coding, args.pops) == (50, 10000, False, 0)
         line = {
             "metric": "alignments/sec", "value": total_aln / dt, "unit": "alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "site_columns_per_sec": total_aln * L / dt,
-            "config": {"workload": f"BASELINE configs[1] shape as a device-resident batch: {B} distinct alignments "
-                                   f"per GPU per step, N={N} x L={L}, theta={args.theta}, "
-                                   f"{'coding (--cds)' if args.coding else 'non-coding'}"
-                                   + (f", {K} populations of {N} rows per matrix" if args.pops else ""),
-                       "rows": N, "sites": L, "batch_per_gpu": B, "row_stride": stride,
-                       "parallelism": f"independent alignments sharded over {world} rank(s); one RCCL all-gather of result records"
-                                      if world > 1 else "single GPU",
-                       "kernel_variant": {0: "lds_dma_nt", 1: "register_staged", 2: "lds_dma_default_policy"}[args.variant],
+            "config": {"workload": ("BASELINE configs[1] shape as a device-resident batch: " if default_shape else "device-resident batch: ")
+                                   + hw.label() + f" per GPU per step, theta={args.theta}",
+                       "rows": N, "sites": L, "batch_per_gpu": B, "row_stride": hw.stride,
+                       "parallelism": f"independent alignments sharded over {world} rank(s), one process per GPU; one RCCL "
+                                      f"all-gather of the result records (pfa_comm_all_gather_results)" if world > 1 else "single GPU",
+                       "kernel_variant": {0: "lds_dma_nt", 2: "lds_dma_default_policy"}[args.variant],
                        "tiles_per_chunk": plan.tiles_per_chunk, "lds_bytes_per_wave": plan.lds_bytes,
-                       "rows_per_chunk": plan.rows_per_chunk},
+                       "rows_per_chunk": plan.rows_per_chunk, "tile_width": plan.tile_width},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "pfa::scan_tall_kernel" if plan.rows_per_chunk else "pfa::scan_kernel", "kernel_ms_avg": k_avg_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": plan.description, "kernel_ms_avg": k_avg_ms,
+                         "algorithmic_bytes_per_launch": hw.alg_bytes,
                          "frac_of_measured_copy_6290": achieved / 6290.0,
                          # best plain streaming read measured on this pool (tools/ubench/read_stream.hip)
                          "frac_of_measured_read_6860": achieved / 6860.0},
@@ -239,35 +395,29 @@ def main():
                           "kernel_ms_min": float(kms.min()), "kernel_ms_max": float(kms.max())},
             "check": {"mean_seg_sites": float(res["seg_sites"].mean()),
                       "sum_H": int(res["H"].sum()),
-                      "gathered_records": None if gathered is None else int(len(gathered))},
+                      "gathered_records": None if gathered is None else int(gathered.size),
+                      "gathered_rank0_equals_fetch": None if gathered is None else bool((gathered[0] == res).all())},
         }
-        line["roofline"]["traffic"] = measured_traffic(line["config"])
-        if world == 1 and not args.coding and not args.pops and not args.no_cpu_baseline:   # (not under the profiler)
-            # BASELINE configs[1] literally: ONE alignment per launch (latency-bound: 500 KB of bases)
-            one = scan.Plan(scan.finalize_layout(descs[:1].copy(), None, nbytes))
-            for _ in range(20):
-                one.run(dev)
-            _lib.check(lib.pfa_sync())
-            t1 = time.perf_counter()
-            for _ in range(200):
-                one.run(dev)
-                one.fetch()
-            per = (time.perf_counter() - t1) / 200
-            line["single_alignment"] = {"us_per_scan_and_fetch": per * 1e6, "kernel_us": float(one.kernel_ms(50).mean()) * 1e3,
-                                        "note": "one N x L alignment per launch, bases resident, records fetched after every scan"}
-            one.close()
-        if world == 1 and not args.no_cpu_baseline and not args.coding and not args.pops:
-            cb, (s_cpu, h_cpu) = cpu_baseline(args, params)
+        line["roofline"]["traffic"], line["roofline"]["traffic_source"] = measured_traffic(line["config"])
+        extras = world == 1 and comm is None and not args.no_extras and default_shape
+        if extras and not args.no_cpu_baseline:
+            cb, (s_cpu, h_cpu) = cpu_baseline(args, hw)
             line["cpu_baseline"] = cb
             # the CPU sample is the first 128 alignments of rank 0's batch: integers must agree
             line["check"]["cpu_sample_matches_gpu"] = bool(
                 (res["seg_sites"][:len(s_cpu)] == s_cpu).all() and (res["H"][:len(h_cpu)] == h_cpu).all())
+        if extras:
+            line.update(small_launches(hw, args))
+            hw.close()
+            line["workloads"] = extra_workloads(args)
+            line["end_to_end"] = end_to_end(args)
+        else:
+            hw.close()
         print(json.dumps(line), flush=True)
-
-    plan.close()
-    dev.free()
-    if dist is not None:
-        dist.destroy_process_group()
+    else:
+        hw.close()
+    if comm is not None:
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 2
+#define PFA_ABI_VERSION 3
 
 /* error codes */
 #define PFA_OK 0
@@ -46,12 +46,14 @@ extern "C" {
 #define PFA_ERR_NOMEM (-6)
 #define PFA_ERR_FORMAT (-7)     /* FASTA packer: not FASTA / unsupported byte */
 #define PFA_ERR_IO (-8)
+#define PFA_ERR_UNSUPPORTED (-9) /* FASTA packer: a byte >= 0x80 in a sequence line */
 
 /* Rows per scan unit.  Units with many rows are streamed in row chunks, so the
- * bound is what the counters hold: 32 bits for non-coding units, 24 bits for the
- * per-site H of a coding unit (PFA_FLAG_CDS). */
+ * bound is what the 32-bit allele counters are sized for; coding units
+ * (PFA_FLAG_CDS) share it: above 2 048 rows their per-site H is kept in 56 bits
+ * (the reference's getvarCDSsites has no row limit, PolyFastA.py:284-315). */
 #define PFA_MAX_ROWS 1048576u
-#define PFA_MAX_ROWS_CDS 2048u
+#define PFA_MAX_ROWS_CDS PFA_MAX_ROWS
 
 #define PFA_NO_ROW_IDX 0xFFFFFFFFu
 
@@ -62,9 +64,8 @@ extern "C" {
 #define PFA_WANT_VAR_BITMAP 1u /* variable-site bitmap  -> `pos` of getvarsites        */
 #define PFA_WANT_SN_BITMAP 2u  /* S / N position bitmaps -> lists of getvarCDSsites    */
 
-/* Column-tile width (sites per wavefront tile): 256 for every plan (units with
- * many rows stream their rows in chunks instead of narrowing the tile).  Query
- * with pfa_tile_sites().  Bitmaps are laid out per tile. */
+/* Bitmaps and pfa_desc.tile_off are laid out per 256-site tile (whatever tile
+ * width the kernel that serves a unit works on; pfa_plan_describe()). */
 #define PFA_TILE_SITES 256u
 
 /* One scan unit = one alignment, or one population's row subset of an
@@ -108,10 +109,9 @@ typedef struct pfa_result {
 
 typedef struct pfa_plan pfa_plan;
 
-/* tile geometry of a plan whose largest unit has `max_rows` rows and that holds
- * (`cds` = 1) or does not hold (0) a coding unit: sites per tile (256) and 64-bit
- * words per tile of every bitmap (4).  tile_off of unit i = sum over earlier units
- * of ceil(n_sites / pfa_tile_sites(max_rows, cds)). */
+/* bitmap geometry: sites per tile (PFA_TILE_SITES, whatever the arguments) and
+ * 64-bit words per tile of every bitmap (4).  tile_off of unit i = sum over
+ * earlier units of ceil(n_sites / PFA_TILE_SITES). */
 uint32_t pfa_tile_sites(uint32_t max_rows, uint32_t cds);
 uint32_t pfa_var_words_per_tile(uint32_t max_rows, uint32_t cds);
 
@@ -119,6 +119,7 @@ uint32_t pfa_var_words_per_tile(uint32_t max_rows, uint32_t cds);
 int pfa_abi_version(void);
 int pfa_device_count(void);
 int pfa_init(int device);
+int pfa_device_index(void); /* the device pfa_init() bound, or -1 */
 void pfa_shutdown(void);
 const char* pfa_last_error(void);
 int pfa_sync(void);
@@ -135,30 +136,45 @@ int pfa_download(void* dst_host, const void* src_dev, size_t bytes);
 
 /* ---- scan plans ------------------------------------------------------------
  * A plan validates and uploads a descriptor table and owns the device-side
- * output buffers; it can be run any number of times on device-resident bases. */
+ * output buffers; it can be run any number of times on device-resident bases.
+ * Its units are sorted into buckets by the kernel that suits them (row count,
+ * coding or not, row-index list or not): one launch per bucket, so a few
+ * many-row alignments do not slow a batch of small ones down. */
 int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc,
                     const uint32_t* row_idx, size_t n_row_idx,
                     uint64_t n_bases_bytes, uint32_t want, pfa_plan** out);
 /* launch on the context stream; asynchronous; returns after enqueue.
- * `variant`: 0 = default kernel (LDS-DMA staging, non-temporal loads: the bases
- * are read once), 1 = register-staged tile, 2 = LDS-DMA with the default cache
- * policy (1 and 2 exist for A/B measurements) */
+ * `variant`: 0 = default kernels (LDS-DMA staging, non-temporal loads: the bases
+ * are read once), 2 = the same with the default cache policy (A/B measurements;
+ * 256-site-tile launches only) */
 int pfa_plan_run(pfa_plan* plan, const uint8_t* d_bases, int variant);
-/* elapsed milliseconds (HIP events on the launch stream) of the scan kernel of
- * the most recent `n` runs, oldest first; returns the count written or <0 */
+/* record HIP events around the scan launches of every later run (off by default:
+ * two event records cost more than a small scan) */
+int pfa_plan_set_timing(pfa_plan* plan, int on);
+/* elapsed milliseconds (HIP events on the launch stream) of the scan launches of
+ * the most recent `n` timed runs, oldest first; returns the count written or <0 */
 int pfa_plan_kernel_ms(pfa_plan* plan, float* ms_out, int n);
 /* synchronise and copy outputs to host; any pointer may be NULL.
  * sizes: results[n_desc], sfs[sfs_words], syn_num[n_desc*PFA_SYN_BINS],
- *        every bitmap: n_tiles * pfa_var_words_per_tile() uint64 (tile-interleaved, below) */
+ *        every bitmap: n_tiles * pfa_var_words_per_tile() uint64 (tile-interleaved, below).
+ * The first fetch after a run moves records, SFS and synonymous bins to the host
+ * and clears them on the device for the next run; later fetches of the same run
+ * are served from the host copy. */
 int pfa_plan_fetch(pfa_plan* plan, pfa_result* results, uint32_t* sfs, uint32_t* syn_num,
                    uint64_t* var_bitmap, uint64_t* syn_bitmap, uint64_t* non_bitmap);
-/* device pointer of the result records (n_desc x pfa_result), e.g. to hand to
- * an RCCL gather without a host round trip */
+/* device pointer of the result records (n_desc x pfa_result) of the last run,
+ * valid until that run is fetched (pfa_comm_all_gather_results() reads them) */
 int pfa_plan_results_dev(pfa_plan* plan, void** d_results, size_t* bytes);
 uint32_t pfa_plan_n_tiles(const pfa_plan* plan);
-uint32_t pfa_plan_tiles_per_chunk(const pfa_plan* plan); /* launch geometry, for reports */
+/* launch geometry of the plan's largest bucket (by bases read), for reports */
+uint32_t pfa_plan_tiles_per_chunk(const pfa_plan* plan);
 uint32_t pfa_plan_lds_bytes(const pfa_plan* plan);
 uint32_t pfa_plan_rows_per_chunk(const pfa_plan* plan); /* 0: all rows of a tile at once */
+uint32_t pfa_plan_tile_width(const pfa_plan* plan);     /* sites per tile: 256, 128 or 64 */
+uint32_t pfa_plan_n_launches(const pfa_plan* plan);     /* buckets = kernel launches per run */
+/* one line per bucket, largest first: kernel instantiation, units, LDS bytes, chunking
+ * (owned by the plan) */
+const char* pfa_plan_describe(const pfa_plan* plan);
 uint64_t pfa_plan_sfs_words(const pfa_plan* plan);
 void pfa_plan_destroy(pfa_plan* plan);
 
@@ -168,6 +184,32 @@ int pfa_scan_batch(const uint8_t* bases, uint64_t n_bases_bytes,
                    const uint32_t* row_idx, size_t n_row_idx,
                    pfa_result* results, uint32_t* sfs, uint32_t* syn_num,
                    uint64_t* var_bitmap, uint64_t* syn_bitmap, uint64_t* non_bitmap);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------
+ * The reference's --dir loop over files (PolyFastA.py:104) is embarrassingly
+ * parallel: every rank scans its own share of the alignments, nothing is
+ * exchanged on the data path, and the fixed-size integer records are gathered
+ * once at the end.  RCCL is loaded on the first of these calls only.  Rank 0
+ * makes the unique id; the host language carries its PFA_COMM_ID_BYTES bytes to
+ * the other ranks (file, socket, launcher store), then every rank — after
+ * pfa_init(device) — calls pfa_comm_init().  Collectives run on the context
+ * stream, i.e. behind the scans enqueued before them. */
+#define PFA_COMM_ID_BYTES 128
+int pfa_comm_unique_id(uint8_t* id_out /* PFA_COMM_ID_BYTES */);
+int pfa_comm_init(int rank, int world, const uint8_t* id);
+int pfa_comm_rank(void);
+int pfa_comm_world(void);
+int pfa_comm_barrier(void);                 /* returns when every rank has arrived */
+int pfa_comm_all_reduce_max(double* x);     /* in place; e.g. the slowest rank's wall time */
+/* `bytes_per_rank` bytes from every rank, in rank order, to every rank (host buffers,
+ * staged through device memory; recv_host holds world x bytes_per_rank) */
+int pfa_comm_all_gather(const void* send_host, void* recv_host, size_t bytes_per_rank);
+/* the result records of the plan's last run, of every rank, straight from device
+ * memory (no host round trip before the collective); every rank's plan must hold
+ * the same number of units; out: world x n_desc records; call it before
+ * pfa_plan_fetch() */
+int pfa_comm_all_gather_results(pfa_plan* plan, pfa_result* out);
+int pfa_comm_destroy(void);
 
 /* Bitmap layout ("tile-interleaved", the order the wavefront ballots produce),
  * the same for the variable-site, synonymous and non-synonymous bitmaps:
@@ -234,12 +276,15 @@ int pfa_fasta_pack(const uint8_t* text, uint64_t n_text, const pfa_fasta_rec* re
  * PFA_FILE_NOT_FASTA, PFA_FILE_UNEQUAL (sequences of different lengths; the
  * reference prints a comment line for both, PolyFastA.py:135-140,246-248),
  * PFA_FILE_DEFERRED = did not fit this call's buffer (submit it again; when it
- * is larger than `cap`, row_stride holds the needed bytes / 256), PFA_ERR_IO =
- * unreadable.  names_out (optional): the record names of file i, each
+ * is larger than `cap`, row_stride holds the needed bytes / 256),
+ * PFA_FILE_UNSUPPORTED = non-ASCII bytes in sequence lines (this file only; the
+ * others of the call are packed), PFA_ERR_IO = unreadable or not a regular file
+ * (e.g. a sub-directory of --dir).  names_out (optional): the record names of file i, each
  * NUL-terminated, back to back from info[i].names_off (--pops matching). */
 #define PFA_FILE_NOT_FASTA 1
 #define PFA_FILE_UNEQUAL 2
 #define PFA_FILE_DEFERRED 3
+#define PFA_FILE_UNSUPPORTED 4 /* bytes >= 0x80 in sequence lines: outside one byte per base */
 typedef struct pfa_file_info {
   int32_t status;
   uint32_t n_rows;

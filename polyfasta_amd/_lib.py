@@ -12,16 +12,17 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpfa_hip.so")
+LIB_PATH = os.environ.get("PFA_LIB") or os.path.join(_HERE, "libpfa_hip.so")   # PFA_LIB: timing experiments with other builds
 
-PFA_ABI_VERSION = 2
+PFA_ABI_VERSION = 3
 PFA_NO_ROW_IDX = 0xFFFFFFFF
 PFA_FLAG_CDS = 1
 PFA_WANT_VAR_BITMAP = 1
 PFA_WANT_SN_BITMAP = 2
 PFA_SYN_BINS = 65
 PFA_MAX_ROWS = 1 << 20
-PFA_MAX_ROWS_CDS = 2048
+PFA_MAX_ROWS_CDS = PFA_MAX_ROWS
+PFA_COMM_ID_BYTES = 128
 PFA_ERR_FORMAT = -7
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -50,7 +51,9 @@ FILE_INFO_DTYPE = np.dtype([
 PFA_FILE_NOT_FASTA = 1
 PFA_FILE_UNEQUAL = 2
 PFA_FILE_DEFERRED = 3
+PFA_FILE_UNSUPPORTED = 4
 PFA_ERR_IO = -8
+PFA_ERR_UNSUPPORTED = -9
 assert FILE_INFO_DTYPE.itemsize == 32
 assert DESC_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 56 and FASTA_REC_DTYPE.itemsize == 32
 
@@ -78,6 +81,7 @@ _PROTOTYPES = {
     "pfa_abi_version": (ctypes.c_int, []),
     "pfa_device_count": (ctypes.c_int, []),
     "pfa_init": (ctypes.c_int, [ctypes.c_int]),
+    "pfa_device_index": (ctypes.c_int, []),
     "pfa_shutdown": (None, []),
     "pfa_last_error": (ctypes.c_char_p, []),
     "pfa_sync": (ctypes.c_int, []),
@@ -91,6 +95,7 @@ _PROTOTYPES = {
     "pfa_plan_create": (ctypes.c_int, [_vp, ctypes.c_uint32, _vp, ctypes.c_size_t, ctypes.c_uint64,
                                        ctypes.c_uint32, ctypes.POINTER(_vp)]),
     "pfa_plan_run": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+    "pfa_plan_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pfa_plan_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
     "pfa_plan_fetch": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pfa_plan_results_dev": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_size_t)]),
@@ -98,6 +103,9 @@ _PROTOTYPES = {
     "pfa_plan_tiles_per_chunk": (ctypes.c_uint32, [_vp]),
     "pfa_plan_lds_bytes": (ctypes.c_uint32, [_vp]),
     "pfa_plan_rows_per_chunk": (ctypes.c_uint32, [_vp]),
+    "pfa_plan_tile_width": (ctypes.c_uint32, [_vp]),
+    "pfa_plan_n_launches": (ctypes.c_uint32, [_vp]),
+    "pfa_plan_describe": (ctypes.c_char_p, [_vp]),
     "pfa_plan_sfs_words": (ctypes.c_uint64, [_vp]),
     "pfa_plan_destroy": (None, [_vp]),
     "pfa_scan_batch": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint32, _vp, ctypes.c_size_t,
@@ -120,6 +128,15 @@ _PROTOTYPES = {
                                             ctypes.c_uint64, _vp, _vp, ctypes.c_uint64, u64p, u64p]),
     "pfa_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "pfa_host_free": (ctypes.c_int, [_vp]),
+    "pfa_comm_unique_id": (ctypes.c_int, [_vp]),
+    "pfa_comm_init": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp]),
+    "pfa_comm_rank": (ctypes.c_int, []),
+    "pfa_comm_world": (ctypes.c_int, []),
+    "pfa_comm_barrier": (ctypes.c_int, []),
+    "pfa_comm_all_reduce_max": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double)]),
+    "pfa_comm_all_gather": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
+    "pfa_comm_all_gather_results": (ctypes.c_int, [_vp, _vp]),
+    "pfa_comm_destroy": (ctypes.c_int, []),
 }
 
 _lib = None
@@ -160,13 +177,17 @@ def check(rc):
 
 
 def init(device=None):
-    """Bind this process to one GPU (default: LOCAL_RANK or 0).  Raises without a gfx950 device."""
+    """Bind this process to one GPU: `device`, else LOCAL_RANK (one process per GPU), else 0.
+    Raises without a gfx950 device, and when LOCAL_RANK names a device that is not there —
+    ranks never share a GPU silently (PFA_ALLOW_SHARED_GPU=1: rehearsals on a one-GPU box)."""
     global _device
     lib = load()
     if device is None:
-        device = _device if _device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+        if _device is not None:
+            return _device
+        device = int(os.environ.get("LOCAL_RANK", "0"))
         ndev = lib.pfa_device_count()
-        if ndev > 0:
+        if ndev > 0 and device >= ndev and os.environ.get("PFA_ALLOW_SHARED_GPU"):
             device %= ndev
     if _device == device:
         return device

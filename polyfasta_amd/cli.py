@@ -10,7 +10,11 @@ Mirrors ``main`` (PolyFastA.py:13-142), ``print_result`` / ``no_header``
   * ``--pops`` works: the reference crashes on Python 3 at :126
     (``len(filter(...))``); the intended behaviour is implemented (App. A-1 of
     SURVEY.md): substring match of each key in the headers, one row per key;
-  * every scan runs on the GPU; there is no CPU path.
+  * every scan runs on the GPU; there is no CPU path;
+  * two extra flags that do not change the default output: ``--gpus N`` (one process per
+    GPU, files split by size, records gathered with RCCL) and ``--sfs`` (appends the folded
+    site-frequency spectrum of ``getsfs``, PolyFastA.py:274-282, which the reference's epilog
+    advertises but never prints).
 """
 from __future__ import annotations
 
@@ -22,7 +26,7 @@ import numpy as np
 
 from . import fasta, stats
 from ._lib import (DESC_DTYPE, PFA_ERR_IO, PFA_FILE_DEFERRED, PFA_FILE_NOT_FASTA, PFA_FILE_UNEQUAL,
-                   PFA_FLAG_CDS, PFA_NO_ROW_IDX)
+                   PFA_FILE_UNSUPPORTED, PFA_FLAG_CDS, PFA_NO_ROW_IDX)
 from .scan import Batch, DeviceBuffer, Plan, finalize_layout, scan_batch
 
 HEADER_PLAIN = "file,seqlen,pop,N,seg_sites,pi,theta,tajimasD"
@@ -94,10 +98,10 @@ class Sink:
         self.out, self.silent = out, silent
         self._pending = []
 
-    def header(self, cds):
+    def header(self, cds, sfs=False):
         if self.silent:
             return
-        text = HEADER_CDS if cds else HEADER_PLAIN
+        text = (HEADER_CDS if cds else HEADER_PLAIN) + (",sfs" if sfs else "")
         if self.out:
             with open(self.out, "w") as o:      # PolyFastA.py:103 -> :215/:222 ("w")
                 o.write(text + "\n")
@@ -162,6 +166,10 @@ def build_parser():
     p.add_argument("--silent", "-s", action="store_true", default=False, help="suppress header and verbose output.")
     p.add_argument("--name", "-n", type=str, default=False, help="name of the DNA region to show in output.")
     p.add_argument("--jc", action="store_true", default=False, help="Jukes-Cantor correction for Pi.")
+    p.add_argument("--gpus", type=int, default=0, metavar="N",
+                   help="(polyfasta_amd) scan on N GPUs of this node: one process per GPU, the files split by size.")
+    p.add_argument("--sfs", action="store_true", default=False,
+                   help="(polyfasta_amd) append a column `sfs`: the folded site-frequency spectrum, bins 1..N/2 joined by ';'.")
     return p
 
 
@@ -197,6 +205,8 @@ def _events_for(fidx, path, name, status, names, n_rows, seqlen, args, add_unit)
         return [(fidx, "stdout", f"# file {path} is not FASTA!")]                   # :247 (always stdout)
     if status == PFA_FILE_UNEQUAL:
         return [(fidx, "comment", f"# Sequences do not have the same length: {name}")]   # :135-140
+    if status == PFA_FILE_UNSUPPORTED:     # this file only: the rest of the batch is scanned (deviations)
+        return [(fidx, "comment", f"# Sequences hold non-ASCII characters (not supported, one byte per base): {name}")]
     if args.cds and seqlen % 3 != 0:                                               # :114-119
         evs.append((fidx, "comment", f"# CDS sequence length is not a multiple of 3: {name}"))
     if not args.pops:                                                              # :120-121
@@ -211,13 +221,19 @@ def _events_for(fidx, path, name, status, names, n_rows, seqlen, args, add_unit)
     return evs
 
 
-def _attach(pending, out, done):
+def _attach(pending, out, done, want_sfs=False):
+    """Unit events get their device record, their bins of synonymous-site numerators and — with
+    --sfs — their folded SFS (None when the reference's getsfs would raise: a variable column
+    with fewer than two A/C/G/T alleles, PolyFastA.py:279-281)."""
     recs = out.results.tolist() if out is not None else None     # tuples of Python ints, one conversion per batch
     for ev in pending:
         if ev[1] == "unit":
             fidx, _, unit, name, pop, n_rows, seqlen = ev
             syn = out.syn_num[unit] if out.syn_num is not None else None
-            done.append((fidx, "unit", name, pop, n_rows, seqlen, recs[unit], syn))
+            sfs = None
+            if want_sfs and recs[unit][_BAD] == 0:
+                sfs = out.sfs(unit).tolist()
+            done.append((fidx, "unit", name, pop, n_rows, seqlen, recs[unit], syn, sfs))
         else:
             done.append(ev)
 
@@ -229,14 +245,20 @@ def process_files(indexed_paths, args):
     done = []
     if args.pipe:
         for fidx, path in indexed_paths:
-            aln = fasta.read_fasta_stdin(stride_align=128)
-            status = PFA_FILE_NOT_FASTA if aln is None else (0 if aln.same_length else PFA_FILE_UNEQUAL)
+            from ._lib import PFA_ERR_UNSUPPORTED, PfaError
+            try:
+                aln = fasta.read_fasta_stdin(stride_align=128)
+                status = PFA_FILE_NOT_FASTA if aln is None else (0 if aln.same_length else PFA_FILE_UNEQUAL)
+            except PfaError as e:
+                if e.code != PFA_ERR_UNSUPPORTED:
+                    raise
+                aln, status = None, PFA_FILE_UNSUPPORTED
             batch = Batch(stride_align=128)
             mid = batch.add_matrix(aln.matrix) if status == 0 else None
             pending = _events_for(fidx, path, path.split("/")[-1], status, aln.names if aln else None,
                                   aln.n_rows if aln else 0, int(aln.seq_lens[0]) if status == 0 else 0, args,
                                   lambda rows: batch.add_unit(mid, rows=None if rows is None else np.asarray(rows, dtype=np.uint32), cds=args.cds))
-            _attach(pending, scan_batch(batch) if batch.n_units else None, done)
+            _attach(pending, scan_batch(batch) if batch.n_units else None, done, args.sfs)
         return done
 
     from collections import deque
@@ -328,7 +350,7 @@ def process_files(indexed_paths, args):
                 if dev is not None:
                     from . import _lib
                     _lib.check(_lib.load().pfa_sync())
-            _attach(pending, out, done)
+            _attach(pending, out, done, args.sfs)
             if deferred:
                 if len(deferred) == len(chunk):
                     # nothing fitted: the first file alone is larger than the buffer.  Let the ingest in
@@ -435,7 +457,11 @@ def format_cds_rows_native(units, jc):
 NATIVE_ROWS_MIN = 64      # below this the per-row Python path is as fast
 
 
-def emit(events, sink, cds, jc):
+def _sfs_text(sfs):
+    return "NA" if sfs is None else ";".join(map(str, sfs))
+
+
+def emit(events, sink, cds, jc, sfs=False):
     """Finish the floats and write the rows / comment lines in order."""
     i, n = 0, len(events)
     while i < n:
@@ -457,47 +483,51 @@ def emit(events, sink, cds, jc):
                     block = format_plain_rows_native([(e[2], e[3], e[4], e[5], _fields(e[6])) for e in run], jc)
                 elif all(e[7] is not None for e in run):
                     block = format_cds_rows_native([(e[2], e[3], e[4], e[5], _fields(e[6]), e[7]) for e in run], jc)
-            if block is not None and sink.bulk_ok():
+            if block is not None and sink.bulk_ok() and not sfs:
                 sink.rows(block)
             else:
                 rows = block.split("\n") if block is not None else None
                 for k, e in enumerate(run):
-                    _, _, name, pop, n_rows, seqlen, res, syn = e
+                    name, pop, n_rows, seqlen, res, syn = e[2:8]
                     text = rows[k] if rows is not None else (
                         format_cds_row(name, pop, n_rows, seqlen, res, syn, jc) if cds
                         else format_plain_row(name, pop, n_rows, seqlen, res, jc))
+                    if sfs:
+                        text += "," + _sfs_text(e[8])
                     sink.row(text, name, pop)
             i = j
     sink.flush()
 
 
-def gather_events(group, events):
-    """Multi-GPU: the integer records travel through ONE all-gather of fixed-size
-    structs (RCCL on the GPU box); the small text metadata through gather_object.
-    Returns the merged, file-ordered event list on rank 0 (None elsewhere)."""
+def gather_events(comm, events):
+    """Multi-GPU: the integer records (and, for coding runs, the bins of synonymous-site
+    numerators) travel as fixed-size structs through the communicator's all-gather (RCCL on
+    the GPU box), the small text metadata (names, comment lines, --sfs vectors) as one pickled
+    blob per rank.  Returns the merged, file-ordered event list on rank 0 (None elsewhere)."""
     from ._lib import PFA_SYN_BINS, RESULT_DTYPE
     units = [ev for ev in events if ev[1] == "unit"]
     rec = np.zeros(len(units), dtype=RESULT_DTYPE)
-    syn = np.zeros((len(units), PFA_SYN_BINS), dtype=np.uint32)
     if units:
         rec[:] = np.array([_fields(ev[6]) for ev in units], dtype=RESULT_DTYPE)
+    any_syn = any(ev[7] is not None for ev in units)
+    syn = np.zeros((len(units), PFA_SYN_BINS), dtype=np.uint32)
     for i, ev in enumerate(units):
         if ev[7] is not None:
             syn[i] = ev[7]
-    all_rec = group.all_gather_records(rec)
-    all_syn = group.all_gather_records(syn.reshape(-1))
-    meta = [ev[:6] if ev[1] == "unit" else ev for ev in events]      # no numpy payload
-    all_meta = group.gather_objects(meta, dst=0)
-    if group.rank != 0:
+    all_rec = comm.all_gather_records(rec)
+    all_syn = comm.all_gather_records(syn.reshape(-1) if any_syn else syn[:0].reshape(-1))
+    meta = [ev[:6] + (ev[8],) if ev[1] == "unit" else ev for ev in events]      # no numpy payload
+    all_meta = comm.gather_objects(meta, dst=0)
+    if comm.rank != 0:
         return None
     merged = []
-    for r in range(group.world):
+    for r in range(comm.world):
         k = 0
-        syn_r = all_syn[r].reshape(-1, PFA_SYN_BINS)
+        syn_r = all_syn[r].reshape(-1, PFA_SYN_BINS) if len(all_syn[r]) else None
         rec_r = all_rec[r].tolist()
         for seq, ev in enumerate(all_meta[r]):
             if ev[1] == "unit":
-                merged.append((ev[0], r, seq, ev + (rec_r[k], syn_r[k])))
+                merged.append((ev[0], r, seq, ev[:6] + (rec_r[k], syn_r[k] if syn_r is not None else None, ev[6])))
                 k += 1
             else:
                 merged.append((ev[0], r, seq, ev))
@@ -505,7 +535,19 @@ def gather_events(group, events):
     return [t[3] for t in merged]
 
 
-def main(argv=None):
+def _file_sizes(paths):
+    sizes = []
+    for p in paths:
+        try:
+            sizes.append(os.path.getsize(p))
+        except OSError:
+            sizes.append(0)
+    return sizes
+
+
+def main(argv=None, comm=None):
+    """`comm`: a dist.Comm to use instead of RCCL (tests); with WORLD_SIZE > 1 and no `comm`
+    the ranks talk through dist.RcclComm."""
     parser = build_parser()
     args = parser.parse_args(argv)
 
@@ -523,32 +565,44 @@ def main(argv=None):
     if len(args.file) > 0 and args.pipe and not (args.file[0] == "stdin" or args.file[0] == args.name):
         parser.error("A FASTA file or multiple files cannot be used with the --pipe argument.")   # :105-106
 
-    from . import _lib
-    from .dist import Group, env_world, shard_indices
-    rank, _, world = env_world()
+    from . import _lib, dist
+    rank, _, world = dist.env_world()
+    if comm is not None:
+        rank, world = comm.rank, comm.world
+    elif args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU: start them now, before anything here has touched the GPU
+        return dist.spawn_ranks(args.gpus, [sys.executable, "-m", "polyfasta_amd"] + list(sys.argv[1:] if argv is None else argv))
+    elif args.gpus > 1 and world != args.gpus:
+        print(f"polyfasta_amd: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        return 2
     try:                                   # the scan runs on the GPU or not at all: say so before any output
-        _lib.init()                        # LOCAL_RANK modulo the visible devices
-    except (_lib.PfaError, _lib.PfaLibraryError) as e:
+        _lib.init()                        # GPU LOCAL_RANK
+        if comm is None and world > 1:
+            comm = dist.RcclComm()
+    except (_lib.PfaError, _lib.PfaLibraryError, TimeoutError) as e:
         print(f"polyfasta_amd: {e}", file=sys.stderr)
         return 2
-    group = Group() if (world > 1 or os.environ.get("PFA_FORCE_DIST")) else None
 
     sink = Sink(args.out, args.silent)
     if rank == 0:
-        sink.header(args.cds)                                                      # :102-103
+        sink.header(args.cds, args.sfs)                                            # :102-103
     paths = sorted(args.file)                                                      # :104
-    mine = [(i, paths[i]) for i in shard_indices(len(paths), rank, world)] if not args.pipe else \
-        ([(0, paths[0])] if rank == 0 and paths else [])
+    if args.pipe:
+        mine = [(0, paths[0])] if rank == 0 and paths else []
+    elif world > 1:
+        mine = [(i, paths[i]) for i in dist.shard_by_size(_file_sizes(paths), world)[rank]]
+    else:
+        mine = list(enumerate(paths))
     events = process_files(mine, args)
-    if group is not None:
-        events = gather_events(group, events)
-        group.barrier()
+    if comm is not None:
+        events = gather_events(comm, events)
+        comm.barrier()
     if rank == 0:
-        emit(events, sink, args.cds, args.jc)
+        emit(events, sink, args.cds, args.jc, args.sfs)
         if len(args.out) != 0 and not args.silent:                                 # :141-142
             print("")
-    if group is not None:
-        group.close()
+    if comm is not None:
+        comm.close()
     return 0
 
 

@@ -9,13 +9,18 @@
 //   * a repeated name resets its sequence but keeps its first position (dict)
 //   * "not FASTA" when the last header seen is empty / absent      (:246-248)
 // Trailing-whitespace set = the ASCII characters for which Python's
-// str.isspace() is true.  Bytes >= 0x80 are rejected (PFA_ERR_FORMAT): the
-// reference would decode them as UTF-8 and apply Unicode case rules, which is
-// outside this path's one-byte-per-base contract (out of scope).
+// str.isspace() is true.  Header bytes >= 0x80 (UTF-8 sample names) are kept as
+// they are; in SEQUENCE lines they are refused (PFA_ERR_UNSUPPORTED, per file
+// PFA_FILE_UNSUPPORTED): the reference would decode them as UTF-8 and apply
+// Unicode case rules, outside this path's one-byte-per-base contract.
+// No exception and no abort crosses the ABI: every entry point catches.
 #include <stdint.h>
 #include <string.h>
 
 #include <stdio.h>
+#include <sys/stat.h>
+
+#include <new>
 
 #include <algorithm>
 #include <atomic>
@@ -74,7 +79,7 @@ inline uint64_t rstrip_end(const uint8_t* t, uint64_t b, uint64_t e) {
 
 extern "C" {
 
-int64_t pfa_fasta_index(const uint8_t* text, uint64_t n_text, pfa_fasta_rec* recs, uint64_t cap) {
+static int64_t fasta_index_impl(const uint8_t* text, uint64_t n_text, pfa_fasta_rec* recs, uint64_t cap) {
   if (!text && n_text) { pfa::set_error("pfa_fasta_index: text is NULL"); return PFA_ERR_ARG; }
   std::vector<pfa_fasta_rec> out;
   std::unordered_map<std::string_view, size_t> by_name;
@@ -87,8 +92,6 @@ int64_t pfa_fasta_index(const uint8_t* text, uint64_t n_text, pfa_fasta_rec* rec
     if (text[pos] == '>') {
       if (have_head) out[cur].end_off = pos;
       const uint64_t nb = pos + 1, ne = rstrip_end(text, pos + 1 > ln.end ? ln.end : pos + 1, ln.end);
-      for (uint64_t i = nb; i < ne; ++i)
-        if (text[i] >= 0x80) { pfa::set_error("non-ASCII byte 0x%02x in a header at offset %llu", text[i], (unsigned long long)i); return PFA_ERR_FORMAT; }
       std::string_view name(reinterpret_cast<const char*>(text + nb), ne > nb ? ne - nb : 0);
       auto it = by_name.find(name);
       if (it == by_name.end()) {
@@ -132,6 +135,18 @@ int64_t pfa_fasta_index(const uint8_t* text, uint64_t n_text, pfa_fasta_rec* rec
   return (int64_t)out.size();
 }
 
+int64_t pfa_fasta_index(const uint8_t* text, uint64_t n_text, pfa_fasta_rec* recs, uint64_t cap) {
+  try {
+    return fasta_index_impl(text, n_text, recs, cap);
+  } catch (const std::bad_alloc&) {
+    pfa::set_error("pfa_fasta_index: out of host memory");
+    return PFA_ERR_NOMEM;
+  } catch (...) {
+    pfa::set_error("pfa_fasta_index: unexpected exception");
+    return PFA_ERR_ARG;
+  }
+}
+
 int pfa_fasta_pack(const uint8_t* text, uint64_t n_text, const pfa_fasta_rec* recs, uint64_t n_recs,
                    uint8_t* bases_out, uint32_t row_stride) {
   if (!text || !recs || !bases_out) { pfa::set_error("pfa_fasta_pack: NULL argument"); return PFA_ERR_ARG; }
@@ -149,7 +164,7 @@ int pfa_fasta_pack(const uint8_t* text, uint64_t n_text, const pfa_fasta_rec* re
       if (w + (e - ln.begin) > r.seq_len) { pfa::set_error("pfa_fasta_pack: record %llu longer than indexed", (unsigned long long)i); return PFA_ERR_ARG; }
       if (copy_upper(row + w, text + ln.begin, e - ln.begin) & 0x80u) {
         pfa::set_error("non-ASCII byte in a sequence line of record %llu (one byte per base only)", (unsigned long long)i);
-        return PFA_ERR_FORMAT;
+        return PFA_ERR_UNSUPPORTED;
       }
       w += e - ln.begin;
       pos = ln.next;
@@ -188,7 +203,9 @@ int pfa_fasta_load_files(const char* const* paths, uint32_t n_files, uint32_t st
     return true;
   };
 
-  auto worker = [&]() {
+  // files above this size are refused (PFA_ERR_IO) instead of attempted
+  constexpr uint64_t kMaxFileBytes = 1ull << 40;
+  auto worker_body = [&]() {
     std::vector<uint8_t> text;
     std::vector<pfa_fasta_rec> recs;
     for (;;) {
@@ -198,10 +215,14 @@ int pfa_fasta_load_files(const char* const* paths, uint32_t n_files, uint32_t st
       memset(&fi, 0, sizeof(fi));
       FILE* fh = fopen(paths[i], "rb");
       if (!fh) { fi.status = PFA_ERR_IO; continue; }
-      fseek(fh, 0, SEEK_END);
-      const long sz = ftell(fh);
-      fseek(fh, 0, SEEK_SET);
-      if (sz < 0) { fclose(fh); fi.status = PFA_ERR_IO; continue; }
+      // only regular files have a size to trust (a directory opens fine and ftell()s LONG_MAX)
+      struct stat sb;
+      if (fstat(fileno(fh), &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 0 || (uint64_t)sb.st_size > kMaxFileBytes) {
+        fclose(fh);
+        fi.status = PFA_ERR_IO;
+        continue;
+      }
+      const long sz = (long)sb.st_size;
       if (text.size() < (size_t)sz) text.resize((size_t)sz);
       const size_t got = sz > 0 ? fread(text.data(), 1, (size_t)sz, fh) : 0;
       fclose(fh);
@@ -242,7 +263,9 @@ int pfa_fasta_load_files(const char* const* paths, uint32_t n_files, uint32_t st
       }
       if (fi.status == 0 && fi.n_rows) {
         const int rc = pfa_fasta_pack(text.data(), (uint64_t)sz, recs.data(), recs.size(), bases_out + off, fi.row_stride);
-        if (rc != PFA_OK) {
+        if (rc == PFA_ERR_UNSUPPORTED) {
+          fi.status = PFA_FILE_UNSUPPORTED;     // this file only; its buffer space stays unused
+        } else if (rc != PFA_OK) {
           std::lock_guard<std::mutex> g(msg_mu);
           hard_rc = rc;
           hard_msg = std::string(paths[i]) + ": " + pfa_last_error_local();
@@ -250,11 +273,33 @@ int pfa_fasta_load_files(const char* const* paths, uint32_t n_files, uint32_t st
       }
     }
   };
-  {
+  // nothing may leave a thread: an exception there would end the process (std::terminate)
+  auto worker = [&]() {
+    try {
+      worker_body();
+    } catch (const std::bad_alloc&) {
+      std::lock_guard<std::mutex> g(msg_mu);
+      hard_rc = PFA_ERR_NOMEM;
+      hard_msg = "pfa_fasta_load_files: out of host memory";
+      next.store(n_files);
+    } catch (...) {
+      std::lock_guard<std::mutex> g(msg_mu);
+      hard_rc = PFA_ERR_ARG;
+      hard_msg = "pfa_fasta_load_files: unexpected exception";
+      next.store(n_files);
+    }
+  };
+  try {
     std::vector<std::thread> th;
+    struct Joiner {
+      std::vector<std::thread>& t;
+      ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); }
+    } joiner{th};
     for (uint32_t t = 1; t < nt; ++t) th.emplace_back(worker);
     worker();
-    for (auto& t : th) t.join();
+  } catch (...) {      // thread creation failed: the threads that did start have been joined
+    pfa::set_error("pfa_fasta_load_files: cannot start the loader threads");
+    return PFA_ERR_NOMEM;
   }
   if (hard_rc != 0) { pfa::set_error("%s", hard_msg.c_str()); return hard_rc; }
   *bytes_used = used.load();

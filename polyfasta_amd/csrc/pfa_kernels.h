@@ -1,0 +1,426 @@
+// pfa_kernels.h — device code shared by the scan kernels of libpfa_hip.so (gfx950 only):
+// LDS layouts, wavefront helpers, the wave-uniform codon-set classifier and the coding pass.
+//
+// What the kernels compute (all integers), per scan unit of N rows:
+//   S      = number of site columns with more than one distinct byte   PolyFastA.py:252-261
+//   H      = sum over those columns of (N^2 - sum_j c_j^2)              PolyFastA.py:485-492
+//   SFS    = histogram of the second-largest A/C/G/T allele count        PolyFastA.py:274-282
+//   coding = per codon column the set of distinct clean codons -> nstops,
+//            missing columns, synonymous-site numerators, and the S / N label
+//            of each variable codon position with the H of its site       PolyFastA.py:284-315,319-434
+//
+// Kernel shape.  One 64-lane wavefront per workgroup; no inter-wave
+// synchronisation anywhere.  A wavefront owns a chunk of consecutive column tiles of one
+// unit; partial sums leave through integer atomics (order-independent).
+//   pfa_scan_classic.hip  scan_kernel: all N rows of a tile in LDS (tiles of 256, 128 or 64 sites)
+//   pfa_scan_tall.hip     scan_tall_kernel: units with many rows, streamed in row chunks
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "pfa_codon.h"
+#include "pfa_common.h"
+#include "pfa_layout.h"
+
+namespace pfa {
+static constexpr ct::Tables kHostTables = ct::make_tables();   // also the source of literal constants in device code
+}
+
+// one copy per translation unit (the library is built without relocatable device code)
+static __constant__ pfa::ct::Tables d_tables = pfa::ct::make_tables();
+static __constant__ pfa::SingleLut d_single_lut = pfa::make_single_lut();
+
+namespace pfa {
+
+// The kernel arguments once more, straight from the kernarg segment.  Pointers that are only
+// needed after the tile loop (results, sfs, syn_num) are read through this at their point of use:
+// an s_load there is cheaper than keeping them in scalar registers across the loop (the scan
+// kernels are short of SGPRs), and the empty asm keeps the compiler from merging these loads
+// with the prologue's.
+typedef const __attribute__((address_space(4))) ScanArgs* kernarg_ptr_t;
+__device__ __forceinline__ kernarg_ptr_t kernargs_again() {
+  kernarg_ptr_t p = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// H and allele-presence mask (which of A, C, T, G occur: codon base order) of a variable site,
+// as the coding pass reads them; HT = uint32_t, or unsigned long long for units above 2 048 rows
+template <class HT>
+struct HMask {
+  HT h;
+  uint32_t m;
+};
+
+// ---------------------------------------------------------------- device helpers
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ inline uint32_t mbcnt64(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+}
+__device__ inline uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ inline unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// sum over the 4 lanes of a quad with DPP quad_perm moves (VALU only; __shfl_xor would go
+// through ds_bpermute and the LDS queue)
+__device__ inline uint32_t quad_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  return v;
+}
+// Workgroups are ONE wavefront: "synchronising" it only means ordering its LDS traffic (lanes
+// exchange data through LDS).  __syncthreads() would also wait for every global load in flight
+// (s_waitcnt vmcnt(0)), i.e. for the tile that was just requested ahead of time.
+__device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// value of the previous lane (lane 0: 0): one DPP move instead of a ds_bpermute
+__device__ inline uint32_t wave_shr1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);   // wave_shr:1
+}
+// OR over the 64 lanes with DPP moves only; the result is wave-uniform (an SGPR pair)
+__device__ inline uint32_t wave_or_uniform(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);   // row_mirror
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ inline unsigned long long wave_or_uniform(unsigned long long v) {
+  return (unsigned long long)wave_or_uniform((uint32_t)v) | (unsigned long long)wave_or_uniform((uint32_t)(v >> 32)) << 32;
+}
+__device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ inline uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+// Wave-uniform form of classify_sense_mask (pfa_codon.h; PolyFastA.py:331-434) for a set `ms`
+// held in scalar registers: lane c stands for codon c (`my_info` = annot_info[c], `my_same` =
+// same_annot[c]), so the multiplicity rule for three or more codons needs no loop — a codon's
+// label multiplicity is one popcount, and "some label occurs at least t times" is one ballot.
+__device__ inline uint32_t classify_uniform(unsigned long long ms, uint32_t lane, uint32_t my_info,
+                                            unsigned long long my_same) {
+  const int k = __popcll(ms);
+  if (k < 2) return 0u;
+  if (k == 2) {
+    const int c1 = __builtin_ctzll(ms);
+    const int c2 = __builtin_ctzll(ms & (ms - 1ull));
+    const uint32_t x = uint32_t(c1 ^ c2);
+    const bool d0 = (x & 0x30u) != 0u, d1 = (x & 0x0Cu) != 0u, d2 = (x & 0x03u) != 0u;
+    if (int(d0) + int(d1) + int(d2) == 1) {                       // PolyFastA.py:349-358
+      const uint32_t i1 = (uint32_t)__builtin_amdgcn_readlane((int)my_info, c1);
+      const uint32_t i2 = (uint32_t)__builtin_amdgcn_readlane((int)my_info, c2);
+      const bool syn = i1 == i2 || (d0 && (i1 & i2 & 0x60u) != 0u);
+      const uint32_t bit = d0 ? 1u : d1 ? 2u : 4u;
+      return syn ? bit : bit << 3;
+    }
+    return d_tables.pair[c1 * 64 + c2];                           // PolyFastA.py:360-414
+  }
+  // three or more distinct sense codons                          PolyFastA.py:415-432
+  uint32_t nb0 = 0, nb1 = 0, nb2 = 0;
+#pragma unroll
+  for (uint32_t e = 0; e < 4u; ++e) {
+    nb0 += (ms & (0xFFFFull << (16u * e))) != 0ull;
+    nb1 += (ms & (0x000F000F000F000Full << (4u * e))) != 0ull;
+    nb2 += (ms & (0x1111111111111111ull << e)) != 0ull;
+  }
+  const uint32_t var = (nb0 > 1u ? 1u : 0u) | (nb1 > 1u ? 2u : 0u) | (nb2 > 1u ? 4u : 0u);
+  const bool present = (ms >> lane) & 1ull;
+  const uint32_t mult = present ? (uint32_t)__popcll(ms & my_same) : 0u;
+  if (__ballot(mult >= 2u) == 0ull) return var << 3;              // all labels distinct: PolyFastA.py:430-432
+  const uint32_t last = (var & 4u) ? 2u : (var & 2u) ? 1u : 0u;
+  const uint32_t nb_last = last == 2u ? nb2 : last == 1u ? nb1 : nb0;
+  const uint32_t s = __ballot(mult >= nb_last) != 0ull ? (1u << last) : 0u;   // PolyFastA.py:426-427
+  const uint32_t n = var & ((1u << last) - 1u);                   // PolyFastA.py:428-429
+  return s | n << 3;
+}
+
+
+// ---------------------------------------------------------------- the coding pass
+// Everything the syn / nonsyn split does once the allele scan of a tile is complete
+// (PolyFastA.py:284-315, 319-434), shared by scan_kernel and scan_tall_kernel.  Tiles are 256
+// sites wide and line-aligned; 256 = 1 (mod 3), so the first codon of tile t starts
+// t mod 3 sites before it: the tier-1 words of the previous tile's last lane are carried in
+// registers, and chunks of coding plans hold a multiple of 3 tiles, so a chunk always starts
+// on a codon boundary.  What a kernel supplies: the tile's tier-1 words, a reader of the per-site
+// HMask (variable sites only), and a reader of the codon set of one column.
+// BITMAPS: the plan may want the per-site S / N bitmaps (compiled out otherwise).
+template <bool BITMAPS>
+struct CodonPass {
+  static constexpr uint32_t LB = 4u, WW = 64u * LB, NIT = 2u;
+  // wave constants: lane c stands for codon c in the tables below
+  uint32_t lane;
+  uint32_t my_info;               // annot_info[c] (classify_uniform)
+  unsigned long long my_same;     // same_annot[c]
+  uint32_t my_cinfo;              // synonymous-neighbour count | stop << 7, read with ds_bpermute
+  uint32_t my_slut[3];            // the three 256-byte planes of SingleLut, one word per lane each
+  uint32_t* synhist;              // LDS: PFA_SYN_BINS bins of synonymous-site numerators by codon count
+  unsigned long long* syn_bm;     // optional per-site S / N bitmaps
+  unsigned long long* non_bm;
+  uint32_t tile_off;
+  // per-lane partial sums of the chunk
+  uint32_t acc_segS = 0u, acc_segN = 0u, acc_stops = 0u, acc_missing = 0u, acc_syn1 = 0u;
+  unsigned long long acc_HS = 0ull, acc_HN = 0ull;
+  uint32_t carry_va = 0u, carry_vd = 0u;   // tier-1 AND / XOR words of the previous tile's last lane
+  // per tile: the codon columns that END at one of this lane's sites
+  uint32_t xw[2], dw[2];          // 3 consensus bytes, 3 XOR bytes (0 = monomorphic) per candidate column
+  int endo[2];                    // tile-relative site where it ends, or -1
+  uint64_t mjoint[2];             // ballots: columns with two or three variable positions
+  bool single[2], mono[2];
+  uint32_t pv[2];                 // the variable position of a `single` column
+  uint32_t site0;
+
+  __device__ void init(uint32_t lane_, uint32_t* synhist_, const ScanArgs& A, const pfa_desc& D) {
+    lane = lane_;
+    synhist = synhist_;
+    syn_bm = A.syn_bm;
+    non_bm = A.non_bm;
+    tile_off = D.tile_off;
+    my_info = d_tables.annot_info[lane];
+    my_same = d_tables.same_annot[lane];
+    my_cinfo = (uint32_t)d_tables.syn3[lane] | (uint32_t)((d_tables.stop_mask >> lane) & 1ull) << 7;
+#pragma unroll
+    for (uint32_t pl = 0; pl < 3u; ++pl) my_slut[pl] = reinterpret_cast<const uint32_t*>(d_single_lut.v)[pl * 64u + lane];
+  }
+
+  // table entry of another lane (the LDS crossbar, no LDS memory); every lane must be enabled
+  __device__ static uint32_t lane_lookup(uint32_t from_lane, uint32_t mine) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)mine);
+  }
+
+  __device__ void mark_site(bool is_s, int rel_site) const {
+    const uint32_t site = site0 + (uint32_t)rel_site;   // rel_site may be -2..-1: previous tile
+    const uint64_t w = (uint64_t)(tile_off + site / WW) * LB + (site % WW) % LB;
+    atomicOr(&(is_s ? syn_bm : non_bm)[w], 1ull << ((site % WW) / LB));
+  }
+
+  // Register window: every lane looks at the codon columns that END at one of its own sites.
+  // The three bytes (tier-1 AND word = the consensus byte of a monomorphic site) and the three
+  // "varies" flags come from this lane's and the previous lane's tier-1 words (lane 0: the words
+  // carried over from the previous tile): no memory traffic for the 87 % of columns that do not vary.
+  __device__ void window(uint32_t va, uint32_t vd, uint32_t site0_, uint32_t lim) {
+    site0 = site0_;
+    uint32_t pa = wave_shr1(va), pd = wave_shr1(vd);
+    if (lane == 0u) { pa = carry_va; pd = carry_vd; }
+    carry_va = __builtin_amdgcn_readlane(va, 63);
+    carry_vd = __builtin_amdgcn_readlane(vd, 63);
+    const unsigned long long Wa = (unsigned long long)pa | (unsigned long long)va << 32;
+    const unsigned long long Wd = (unsigned long long)pd | (unsigned long long)vd << 32;
+    const uint32_t o1 = (5u - (site0 + 4u * lane) % 3u) % 3u;   // first own site that ends a codon
+#pragma unroll
+    for (uint32_t it = 0; it < 2u; ++it) {
+      const uint32_t o = o1 + 3u * it;
+      const bool has = o < 4u && 4u * lane + o < lim;
+      xw[it] = (uint32_t)(Wa >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
+      dw[it] = (uint32_t)(Wd >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
+      endo[it] = has ? (int)(4u * lane + o) : -1;
+    }
+    mjoint[0] = mjoint[1] = 0ull;
+    single[0] = single[1] = mono[0] = mono[1] = false;
+    pv[0] = pv[1] = 0u;
+#pragma unroll
+    for (uint32_t it = 0; it < NIT; ++it) {
+      bool joint = false;
+      if (endo[it] >= 0) {
+        const uint32_t dv = dw[it];
+        const bool v0 = (dv & 0xFFu) != 0u, v1 = (dv & 0xFF00u) != 0u, v2 = (dv & 0xFF0000u) != 0u;
+        const uint32_t nvar = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
+        joint = nvar >= 2u;                                // rare: the codons must be read row by row
+        single[it] = nvar == 1u;                           // one variable position: resolved from its allele mask
+        mono[it] = nvar == 0u;
+        pv[it] = v0 ? 0u : v1 ? 1u : 2u;
+      }
+      mjoint[it] = __ballot(joint);
+    }
+  }
+
+  // One column with two or three variable positions, given the wave-uniform set `M` of its
+  // distinct clean codons: stop / synonymous-site bookkeeping and the classifier
+  // (PolyFastA.py:301-315,319-434).  `hget(rel)`: HMask of a variable site.
+  template <class HGet>
+  __device__ void joint_finish(unsigned long long M, int rel, HGet hget) {
+    const uint32_t k = (uint32_t)__popcll(M);
+    if (k == 0u) { acc_missing += lane == 0u ? 1u : 0u; return; }
+    constexpr unsigned long long kStop = kHostTables.stop_mask;
+    const uint32_t t3 = (uint32_t)__popcll(M & kHostTables.t_mask[1]) + 2u * (uint32_t)__popcll(M & kHostTables.t_mask[2]) +
+                        3u * (uint32_t)__popcll(M & kHostTables.t_mask[3]) + 4u * (uint32_t)__popcll(M & kHostTables.t_mask[4]);
+    const bool stop = (M & kStop) != 0ull;
+    const uint32_t labels = classify_uniform(M & ~kStop, lane, my_info, my_same);
+    if (lane == 0u) {
+      if (k == 1u) acc_syn1 += t3;
+      else atomicAdd(&synhist[k], t3);
+      acc_stops += stop ? 1u : 0u;
+#pragma unroll
+      for (uint32_t p = 0; p < 3u; ++p) {
+        const bool is_s = (labels >> p) & 1u, is_n = (labels >> (3u + p)) & 1u;
+        if (is_s || is_n) {
+          const auto hs = hget(rel + (int)p).h;
+          if (is_s) { acc_segS += 1u; acc_HS += hs; }
+          else { acc_segN += 1u; acc_HN += hs; }
+          if (BITMAPS && syn_bm != nullptr) mark_site(is_s, rel + (int)p);
+        }
+      }
+    }
+  }
+
+  // Columns with two or three variable positions (~0.6 %), one at a time (rows in LDS):
+  // `read_set(rel)` returns this lane's share of the column's codon-presence set (the kernel reads
+  // one row per lane); the sets are OR-reduced with DPP moves.
+  template <class ReadSet, class HGet>
+  __device__ void joint_columns(ReadSet read_set, HGet hget) {
+#pragma unroll
+    for (uint32_t it = 0; it < NIT; ++it) {
+      for (uint64_t m = mjoint[it]; m != 0ull; m &= m - 1ull) {
+        const uint32_t owner = (uint32_t)__builtin_ctzll(m);
+        const int rel = __builtin_amdgcn_readlane(endo[it], owner) - 2;
+        joint_finish(wave_or_uniform(read_set(rel)), rel, hget);
+      }
+    }
+  }
+
+  // The same, up to four columns per call of `read_sets(rels, n, Mv)` (rows in global memory: one
+  // round trip for all of them).
+  template <class ReadSets, class HGet>
+  __device__ void joint_columns_batched(ReadSets read_sets, HGet hget) {
+    int rels[4] = {0, 0, 0, 0};
+    uint32_t nj = 0u;   // wave-uniform: the slots are filled by scalar code
+    auto flush_batch = [&]() {
+      unsigned long long Mv[4] = {0ull, 0ull, 0ull, 0ull};
+      read_sets(rels, nj, Mv);
+#pragma unroll
+      for (uint32_t c = 0; c < 4u; ++c)
+        if (c < nj) joint_finish(wave_or_uniform(Mv[c]), rels[c], hget);
+      nj = 0u;
+    };
+#pragma unroll
+    for (uint32_t it = 0; it < NIT; ++it) {
+      for (uint64_t m = mjoint[it]; m != 0ull; m &= m - 1ull) {
+        const uint32_t owner = (uint32_t)__builtin_ctzll(m);
+        const int rel = __builtin_amdgcn_readlane(endo[it], owner) - 2;
+        if (nj == 0u) rels[0] = rel; else if (nj == 1u) rels[1] = rel; else if (nj == 2u) rels[2] = rel; else rels[3] = rel;
+        if (++nj == 4u) flush_batch();
+      }
+    }
+    if (nj) flush_batch();
+  }
+
+  // Monomorphic columns and columns with ONE variable position: registers and tables only, so a
+  // kernel calls this after it has requested its next tile.
+  template <class HGet>
+  __device__ void mono_and_single_columns(HGet hget) {
+    // monomorphic: exactly-A/C/G/T test of the three consensus bytes at once (the canonical byte
+    // of the 2-bit code (x >> 1) & 3 is 0x41 + 2 code + 0x0F [code == 2]; a byte is clean iff it
+    // equals it), then one table read: synonymous weight | stop << 7.  Every lane computes and
+    // looks up, so that the ds_bpermute runs with all lanes enabled (a disabled lane would not
+    // supply its table entry).
+#pragma unroll
+    for (uint32_t it = 0; it < NIT; ++it) {
+      const uint32_t w = xw[it];
+      const uint32_t t2 = w & 0x060606u;
+      const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
+      const uint32_t bad = (0x414141u + t2 + (e2 << 4) - e2) ^ w;
+      const uint32_t tt = t2 >> 1;
+      const uint32_t ci = lane_lookup(((tt & 3u) << 4) | ((tt >> 6) & 0xCu) | ((tt >> 16) & 3u), my_cinfo);
+      if (mono[it]) {
+        if (bad == 0u) {
+          acc_syn1 += ci & 7u;
+          acc_stops += ci >> 7;
+        } else {
+          acc_missing += 1u;
+        }
+      }
+    }
+    // One variable position, on the lane that owns the column: the codon set is the consensus
+    // codon with every A/C/G/T allele of that position substituted (rows with another symbol
+    // there hold an unclean codon and drop out, PolyFastA.py:301).  Only that position can be
+    // labelled.  The two fixed bytes are the lane's consensus bytes; the allele mask and H of
+    // the variable site come from the allele scan.  All lanes run it, `valid` marks the lanes
+    // that own such a column (the table reads are ds_bpermute's and need every lane enabled).
+    auto single_col = [&](bool valid, uint32_t w, uint32_t p, int end_rel) {
+      const int rel = valid ? end_rel - 2 : 0;
+      const auto hv = hget(rel + (int)p);
+      const uint32_t am = valid ? hv.m : 0u;
+      // exactly-A/C/G/T test of the two fixed bytes (as above; the byte of position p is meaningless)
+      const uint32_t t2 = w & 0x060606u;
+      const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
+      const uint32_t bad = ((0x414141u + t2 + (e2 << 4) - e2) ^ w) & ~(0xFFu << (8u * p));
+      const uint32_t k = bad ? 0u : (uint32_t)__popc(am);   // distinct clean codons
+      const uint32_t tt = t2 >> 1;
+      const uint32_t c0 = tt & 3u, c1 = (tt >> 8) & 3u, c2 = (tt >> 16) & 3u;
+      const uint32_t b4 = p == 0u ? (c1 << 2 | c2) : p == 1u ? (c0 << 2 | c2) : (c0 << 2 | c1);
+      const uint32_t j = b4 * 16u + (am & 15u);             // entry of plane p
+      const uint32_t w0 = lane_lookup(j >> 2, my_slut[0]), w1 = lane_lookup(j >> 2, my_slut[1]), w2 = lane_lookup(j >> 2, my_slut[2]);
+      const uint32_t v = ((p == 0u ? w0 : p == 1u ? w1 : w2) >> (8u * (j & 3u))) & 0xFFu;
+      if (!valid) return;
+      if (k == 0u) { acc_missing += 1u; return; }
+      const uint32_t t3 = v & 0x1Fu;
+      if (k == 1u) acc_syn1 += t3;
+      else atomicAdd(&synhist[k], t3);
+      acc_stops += (v >> 5) & 1u;
+      const bool is_s = (v & 0x40u) != 0u, is_n = (v & 0x80u) != 0u;
+      const auto hs = hv.h;
+      if (is_s) { acc_segS += 1u; acc_HS += hs; }
+      if (is_n) { acc_segN += 1u; acc_HN += hs; }
+      if (BITMAPS && (is_s || is_n) && syn_bm != nullptr) mark_site(is_s, rel + (int)p);
+    };
+    const bool any1 = single[0] || single[1];
+    if (__any(any1)) {
+      const uint32_t sel = single[0] ? 0u : 1u;
+      single_col(any1, sel ? xw[1] : xw[0], (sel ? pv[1] : pv[0]) % 3u, sel ? endo[1] : endo[0]);
+    }
+    const bool both = single[0] && single[1];            // a lane owning two such columns: rare
+    if (__any(both)) single_col(both, xw[1], pv[1] % 3u, endo[1]);
+  }
+
+  // the trailing 1-2 sites of an alignment whose length is not a multiple of 3 never form a
+  // clean codon (PolyFastA.py:301-305)
+  __device__ void last_tile(uint32_t L) {
+    if ((L % 3u) != 0u && lane == 0u) acc_missing += 1u;
+  }
+
+  // the chunk's partial sums -> the unit's record and its bins of synonymous-site numerators
+  __device__ void flush(uint32_t unit) {
+    acc_segS = wave_sum(acc_segS);
+    acc_segN = wave_sum(acc_segN);
+    acc_stops = wave_sum(acc_stops);
+    acc_missing = wave_sum(acc_missing);
+    acc_syn1 = wave_sum(acc_syn1);
+    acc_HS = wave_sum(acc_HS);
+    acc_HN = wave_sum(acc_HN);
+    const kernarg_ptr_t K = kernargs_again();
+    pfa_result* const R = K->results + unit;
+    uint32_t* const syn_num_unit = K->syn_num + (uint64_t)unit * PFA_SYN_BINS;
+    if (lane == 0u) {
+      if (acc_segS) atomicAdd(&R->seg_S, acc_segS);
+      if (acc_segN) atomicAdd(&R->seg_N, acc_segN);
+      if (acc_stops) atomicAdd(&R->nstops, acc_stops);
+      if (acc_missing) atomicAdd(&R->missing_cols, acc_missing);
+      if (acc_HS) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H_S), acc_HS);
+      if (acc_HN) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H_N), acc_HN);
+      if (acc_syn1) atomicAdd(&syn_num_unit[1], acc_syn1);
+    }
+    wave_lds_sync();
+    for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) {
+      const uint32_t v = synhist[i];
+      if (v) atomicAdd(&syn_num_unit[i], v);
+    }
+  }
+};
+
+// codon of three bytes packed in a word (byte 0 = first base): its index as a one-hot 64-bit set,
+// or 0 when any byte is not exactly A/C/G/T (PolyFastA.py:301)
+__device__ inline unsigned long long codon_bit(uint32_t x0, uint32_t x1, uint32_t x2) {
+  const bool ok = base_clean(x0) && base_clean(x1) && base_clean(x2);
+  return ok ? 1ull << (base_code(x0) * 16u + base_code(x1) * 4u + base_code(x2)) : 0ull;
+}
+
+}  // namespace pfa

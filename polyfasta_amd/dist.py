@@ -1,32 +1,36 @@
-"""One process per GPU: sharding of independent alignments and the final gather.
+"""One process per GPU: sharding of independent alignments, the launcher and the final gather.
 
-The `--dir` batch mode of the reference is an embarrassingly parallel loop over
-files (PolyFastA.py:104).  Here the sorted file list is dealt round-robin to
-the ranks of a `torch.distributed` job (backend "nccl" = RCCL over xGMI on the
-GPU box, "gloo" in CPU tests); no collective touches the data path.  When every
-rank has scanned its share, ONE all-gather moves the fixed-size integer result
-records (and the small coding-sequence bins) to every rank; rank 0 finishes the
-floats and prints the rows in the reference's order.
+The `--dir` batch mode of the reference is an embarrassingly parallel loop over files
+(PolyFastA.py:104).  Here the sorted file list is split over the ranks by size (largest
+first, always to the least loaded rank); no collective touches the data path.  When every
+rank has scanned its share, the fixed-size integer result records travel through ONE RCCL
+all-gather (`pfa_comm_*` of the C ABI, include/pfa.h: librccl over xGMI, bound by the library
+itself — no torch anywhere); rank 0 finishes the floats and prints the rows in the
+reference's order.
 
-torch is used for the process group only (rendezvous + collectives): the scan
-itself never sees a torch type.
+Ranks come from a launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE, e.g.
+`python -m torch.distributed.run`), or from `spawn_ranks()` below (`--gpus N` of the CLI and
+of bench.py).  The 128-byte RCCL unique id goes from rank 0 to the others through a file.
 """
 from __future__ import annotations
 
+import contextlib
+import ctypes
 import os
+import pickle
+import subprocess
+import sys
+import tempfile
+import time
 
 import numpy as np
-
-
-import contextlib
-import sys
 
 
 @contextlib.contextmanager
 def stdout_to_stderr():
     """RCCL prints a version banner on stdout when the first communicator is built;
     stdout carries the CSV rows (or the bench's one JSON line), so file descriptor 1
-    is pointed at stderr while the process group comes up."""
+    is pointed at stderr while the communicator comes up."""
     sys.stdout.flush()
     saved = os.dup(1)
     try:
@@ -39,76 +43,251 @@ def stdout_to_stderr():
 
 
 def env_world():
-    """(rank, local_rank, world) from the launcher's environment (torch.distributed.run)."""
+    """(rank, local_rank, world) from the launcher's environment."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def shard_indices(n_items: int, rank: int, world: int):
-    """Indices of the items rank `rank` owns: round-robin, so that neighbouring
-    (similarly sized) files spread over all GPUs."""
-    return list(range(rank, n_items, world))
+# ---------------------------------------------------------------- sharding
+def shard_by_size(sizes, world: int):
+    """Largest-first greedy split of items (file sizes in bytes) over `world` ranks: every item
+    goes to the rank with the least bytes so far (ties: lowest rank).  Returns one ascending
+    index list per rank; every rank computes the same split from the same sizes."""
+    order = sorted(range(len(sizes)), key=lambda i: (-int(sizes[i]), i))
+    load = [0] * world
+    shards = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        shards[r].append(i)
+        load[r] += max(int(sizes[i]), 1)
+    return [sorted(s) for s in shards]
 
 
-class Group:
-    """Thin wrapper over a torch.distributed process group."""
+def shard_indices(n_items: int, rank: int, world: int, sizes=None):
+    """Indices of the items rank `rank` owns (equal sizes when none are given)."""
+    return shard_by_size(sizes if sizes is not None else [1] * n_items, world)[rank]
 
-    def __init__(self, backend=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.rank, self.local_rank, self.world = env_world()
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        self.backend = backend
-        self.device = torch.device("cuda", self.local_rank) if backend == "nccl" else torch.device("cpu")
-        if not dist.is_initialized():
-            with stdout_to_stderr():
-                if backend == "nccl":
-                    torch.cuda.set_device(self.local_rank)
-                    dist.init_process_group(backend="nccl", device_id=self.device)
-                else:
-                    dist.init_process_group(backend="gloo")
-                self.barrier()          # builds the communicator now (banner, lazy init) rather than mid-output
+
+# ---------------------------------------------------------------- launcher
+def visible_gpu_count():
+    """GPUs this process tree can use, WITHOUT touching the HIP runtime (a launcher must not
+    initialise the GPU before it starts its ranks): the kfd topology, cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None when the topology cannot be read."""
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv, timeout=None) -> int:
+    """Start `n` fresh processes `argv` (one per GPU: RANK = LOCAL_RANK = 0..n-1, WORLD_SIZE = n)
+    and wait for them.  Called before anything in this process has touched the GPU.  Fails
+    loudly (non-zero) when fewer than `n` GPUs are visible: never a silent 1-GPU run.  Returns
+    the largest exit code; when a rank fails the others are terminated."""
+    have = visible_gpu_count()
+    if have is not None and have < n and not os.environ.get("PFA_ALLOW_SHARED_GPU"):
+        print(f"polyfasta_amd: --gpus {n} asked for, {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    rdzv = tempfile.mkdtemp(prefix="pfa_rdzv_")
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PFA_RDZV_FILE=os.path.join(rdzv, "rccl_id"),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(list(argv), env=env, stdin=None if r == 0 else subprocess.DEVNULL))
+    t_end = None if timeout is None else time.time() + timeout
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:
+                    rc = max(rc, code if code > 0 else 1)
+                    for q in live:          # a collective would wait for the dead rank for ever
+                        q.terminate()
+            if t_end is not None and time.time() > t_end:
+                for q in live:
+                    q.terminate()
+                rc = max(rc, 124)
+                t_end = None
+            time.sleep(0.005)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        with contextlib.suppress(OSError):
+            for f in os.listdir(rdzv):
+                os.unlink(os.path.join(rdzv, f))
+            os.rmdir(rdzv)
+    return rc
+
+
+# ---------------------------------------------------------------- unique-id rendezvous
+def _parent_start_time():
+    """Wall-clock start of the parent process (the launcher), or 0.0."""
+    try:
+        with open(f"/proc/{os.getppid()}/stat") as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])       # field 22: starttime
+        with open("/proc/stat") as f:
+            btime = next(int(line.split()[1]) for line in f if line.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, StopIteration, IndexError):
+        return 0.0
+
+
+def rendezvous_path():
+    """Where rank 0 leaves the unique id: PFA_RDZV_FILE (spawn_ranks), else a name all ranks of
+    one launcher derive alike — its rendezvous port, its pid (the ranks' parent), its restart count."""
+    p = os.environ.get("PFA_RDZV_FILE")
+    if p:
+        return p
+    key = "_".join([os.environ.get("MASTER_PORT", "0"), str(os.getppid()),
+                    os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none")])
+    return os.path.join(tempfile.gettempdir(), f"pfa_rccl_id_{os.getuid()}_{key}")
+
+
+def exchange_unique_id(rank: int, make_id, nbytes: int, timeout: float = 300.0) -> bytes:
+    """Rank 0 calls `make_id()` and publishes the bytes (write + rename: readers never see a partial
+    file); the other ranks wait for a file that is not older than their launcher."""
+    path = rendezvous_path()
+    if rank == 0:
+        blob = bytes(make_id())
+        assert len(blob) == nbytes
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(blob)
+        os.replace(tmp, path)
+        return blob
+    t_launcher = _parent_start_time() - 1.0
+    t_end = time.time() + timeout
+    while True:
+        try:
+            st = os.stat(path)
+            if st.st_size == nbytes and st.st_mtime >= t_launcher:
+                with open(path, "rb") as f:
+                    blob = f.read()
+                if len(blob) == nbytes:
+                    return blob
+        except OSError:
+            pass
+        if time.time() > t_end:
+            raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout:.0f} s (is rank 0 alive?)")
+        time.sleep(0.002)
+
+
+# ---------------------------------------------------------------- communicator
+class Comm:
+    """What the CLI and the bench need from a communicator; `RcclComm` is the product's,
+    tests inject others through `cli.main(argv, comm=...)`."""
+    rank = 0
+    world = 1
 
     def barrier(self):
-        if self.backend == "nccl":
-            self.torch.cuda.synchronize()
-        self.dist.barrier()
-
-    def all_gather_records(self, local: np.ndarray) -> list:
-        """All-gather a 1-D structured/plain numpy array whose length differs per
-        rank; returns the list of per-rank arrays (same dtype).  One size
-        exchange + one padded all_gather_into_tensor."""
-        torch, dist = self.torch, self.dist
-        local = np.ascontiguousarray(local)
-        item = local.dtype.itemsize
-        counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
-        mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(counts, mine)
-        counts = counts.cpu().tolist()
-        cap = max(max(counts), 1) * item
-        buf = np.zeros(cap, dtype=np.uint8)
-        buf[:local.nbytes] = local.view(np.uint8).reshape(-1)
-        send = torch.from_numpy(buf).to(self.device)
-        recv = torch.empty(self.world * cap, dtype=torch.uint8, device=self.device)
-        dist.all_gather_into_tensor(recv, send)
-        if self.backend == "nccl":
-            torch.cuda.synchronize()
-        flat = recv.cpu().numpy()
-        return [flat[r * cap:r * cap + counts[r] * item].view(local.dtype).copy() for r in range(self.world)]
-
-    def gather_objects(self, obj, dst=0):
-        """Small python metadata (names, comment lines) to rank `dst`."""
-        out = [None] * self.world if self.rank == dst else None
-        self.dist.gather_object(obj, out, dst=dst)
-        return out
+        raise NotImplementedError
 
     def max_float(self, x: float) -> float:
-        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        raise NotImplementedError
+
+    def all_gather_fixed(self, buf: np.ndarray) -> np.ndarray:
+        """uint8[k] of every rank (same k) -> uint8[world, k]"""
+        raise NotImplementedError
 
     def close(self):
-        if self.dist.is_initialized():
-            self.dist.destroy_process_group()
+        pass
+
+    # ---- built on all_gather_fixed
+    def all_gather_bytes(self, blob: bytes) -> list:
+        """A byte string of any length from every rank, to every rank (one size exchange + one
+        padded all-gather)."""
+        mine = np.array([len(blob)], dtype=np.int64)
+        sizes = self.all_gather_fixed(mine.view(np.uint8)).view(np.int64).reshape(-1)
+        cap = max(int(sizes.max()), 1)
+        cap = (cap + 15) // 16 * 16
+        send = np.zeros(cap, dtype=np.uint8)
+        send[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+        recv = self.all_gather_fixed(send)
+        return [recv[r, :int(sizes[r])].tobytes() for r in range(self.world)]
+
+    def all_gather_records(self, local: np.ndarray) -> list:
+        """A 1-D structured / plain numpy array whose length differs per rank -> per-rank arrays."""
+        local = np.ascontiguousarray(local)
+        blobs = self.all_gather_bytes(local.view(np.uint8).reshape(-1).tobytes())
+        return [np.frombuffer(b, dtype=local.dtype).copy() for b in blobs]
+
+    def gather_objects(self, obj, dst=0):
+        """Small python metadata (names, comment lines) of every rank, on rank `dst`."""
+        blobs = self.all_gather_bytes(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
+        return [pickle.loads(b) for b in blobs] if self.rank == dst else None
+
+
+class RcclComm(Comm):
+    """RCCL through the C ABI (pfa_comm_* in include/pfa.h).  The process is bound to GPU
+    LOCAL_RANK first (`_lib.init`): one rule for the scan and the communicator."""
+
+    def __init__(self):
+        from . import _lib
+        self._lib = _lib
+        self.rank, self.local_rank, self.world = env_world()
+        lib = _lib.load()
+        _lib.init()
+        n = _lib.PFA_COMM_ID_BYTES
+
+        def make_id():
+            buf = (ctypes.c_uint8 * n)()
+            _lib.check(lib.pfa_comm_unique_id(buf))
+            return bytes(buf)
+
+        with stdout_to_stderr():
+            uid = exchange_unique_id(self.rank, make_id, n)
+            _lib.check(lib.pfa_comm_init(self.rank, self.world, (ctypes.c_uint8 * n).from_buffer_copy(uid)))
+            _lib.check(lib.pfa_comm_barrier())     # builds the channels now (banner, lazy init), not mid-output
+        if self.rank == 0 and not os.environ.get("PFA_RDZV_FILE"):
+            with contextlib.suppress(OSError):     # every rank is past its read: the barrier above
+                os.unlink(rendezvous_path())
+
+    def barrier(self):
+        self._lib.check(self._lib.load().pfa_comm_barrier())
+
+    def max_float(self, x: float) -> float:
+        v = ctypes.c_double(float(x))
+        self._lib.check(self._lib.load().pfa_comm_all_reduce_max(ctypes.byref(v)))
+        return float(v.value)
+
+    def all_gather_fixed(self, buf: np.ndarray) -> np.ndarray:
+        send = np.ascontiguousarray(buf, dtype=np.uint8).reshape(-1)
+        recv = np.empty((self.world, len(send)), dtype=np.uint8)
+        self._lib.check(self._lib.load().pfa_comm_all_gather(self._lib.ptr(send), self._lib.ptr(recv), len(send)))
+        return recv
+
+    def all_gather_plan_results(self, plan) -> np.ndarray:
+        """The records of the plan's last run, of every rank, gathered from device memory
+        (call before plan.fetch()): RESULT_DTYPE[world, n_units]."""
+        out = np.empty((self.world, plan.table.n_units), dtype=self._lib.RESULT_DTYPE)
+        self._lib.check(self._lib.load().pfa_comm_all_gather_results(plan.handle, self._lib.ptr(out)))
+        return out
+
+    def close(self):
+        self._lib.load().pfa_comm_destroy()

@@ -54,7 +54,7 @@ def parse_fasta_bytes(data, stride_align: int = 16):
     names = []
     for r in recs:
         o, ln = int(r["name_off"]), int(r["name_len"])
-        names.append((raw[o:o + ln] if raw is not None else buf[o:o + ln].tobytes()).decode("ascii"))
+        names.append((raw[o:o + ln] if raw is not None else buf[o:o + ln].tobytes()).decode("utf-8", "surrogateescape"))
     lens = recs["seq_len"].astype(np.uint32)
     aln = Alignment(names=names, seq_lens=lens)
     if n and aln.same_length:
@@ -102,7 +102,7 @@ def load_files(paths, bases_out: np.ndarray, stride_align: int = 128, want_names
                 names.append([])
                 continue
             o = int(fi["names_off"])
-            names.append([p.decode("ascii") for p in raw[o:].split(b"\0", k)[:k]])
+            names.append([p.decode("utf-8", "surrogateescape") for p in raw[o:].split(b"\0", k)[:k]])
     return info, names, used.value
 
 

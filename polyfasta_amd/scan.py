@@ -203,7 +203,8 @@ class ScanOutput:
 class Plan:
     """A validated, device-resident descriptor table plus its output buffers."""
 
-    def __init__(self, table: UnitTable, want_pos: bool = False, want_sn: bool = False):
+    def __init__(self, table: UnitTable, want_pos: bool = False, want_sn: bool = False, timing: bool = False):
+        """`timing`: record HIP events around the scan launches of every run (kernel_ms)."""
         _lib.init()
         self.table = table
         self.want = (_lib.PFA_WANT_VAR_BITMAP if want_pos else 0) | (_lib.PFA_WANT_SN_BITMAP if want_sn else 0)
@@ -213,6 +214,8 @@ class Plan:
                                                _lib.ptr(table.row_idx) if len(table.row_idx) else None,
                                                len(table.row_idx), table.n_bases_bytes, self.want, ctypes.byref(h)))
         self.handle = h
+        if timing:
+            _lib.check(_lib.load().pfa_plan_set_timing(h, 1))
 
     def run(self, d_bases, variant: int = 0):
         p = d_bases.ptr if isinstance(d_bases, DeviceBuffer) else ctypes.c_void_p(int(d_bases))
@@ -243,6 +246,19 @@ class Plan:
         n = ctypes.c_size_t()
         _lib.check(_lib.load().pfa_plan_results_dev(self.handle, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    @property
+    def description(self) -> str:
+        """one entry per kernel launch of a run (bucket), largest first"""
+        return (_lib.load().pfa_plan_describe(self.handle) or b"").decode()
+
+    @property
+    def n_launches(self) -> int:
+        return int(_lib.load().pfa_plan_n_launches(self.handle))
+
+    @property
+    def tile_width(self) -> int:
+        return int(_lib.load().pfa_plan_tile_width(self.handle))
 
     @property
     def tiles_per_chunk(self) -> int:

@@ -1,0 +1,34 @@
+"""A dist.Comm over torch.distributed's gloo backend — TEST infrastructure only: it lets two
+ranks exercise the product's multi-rank host path (sharding, gather, ordered merge) where
+RCCL cannot run: on CPU, and with two ranks sharing the one GPU of the test box (RCCL
+refuses two ranks on one device).  The product's communicator is dist.RcclComm."""
+import numpy as np
+import torch
+import torch.distributed as td
+
+from polyfasta_amd import dist
+
+
+class GlooComm(dist.Comm):
+    def __init__(self):
+        self.rank, self.local_rank, self.world = dist.env_world()
+        if not td.is_initialized():
+            td.init_process_group(backend="gloo")
+
+    def barrier(self):
+        td.barrier()
+
+    def max_float(self, x):
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_gather_fixed(self, buf):
+        send = torch.from_numpy(np.ascontiguousarray(buf, dtype=np.uint8).reshape(-1).copy())
+        recv = torch.empty(self.world * send.numel(), dtype=torch.uint8)
+        td.all_gather_into_tensor(recv, send)
+        return recv.numpy().reshape(self.world, -1)
+
+    def close(self):
+        if td.is_initialized():
+            td.destroy_process_group()

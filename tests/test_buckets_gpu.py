@@ -1,0 +1,134 @@
+"""Per-unit kernel selection, narrow tiles, wide coding units, --sfs: each against the oracle."""
+import io
+import os
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from polyfasta_amd import _lib, cli, scan, stats, synth
+from tests import _cases as C
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(out, i, m, cds=False, rows=None):
+    mm = m if rows is None else m[np.asarray(rows)]
+    o = c_oracle.scan(mm, cds=cds)
+    r = out.results[i]
+    assert (int(r["seg_sites"]), int(r["H"]), int(r["sfs_bad"])) == (o["S"], o["H"], o["sfs_bad"]), i
+    assert out.sfs(i).tolist() == o["sfs"].tolist(), i
+    if cds:
+        assert (int(r["seg_S"]), int(r["seg_N"]), int(r["H_S"]), int(r["H_N"]), int(r["nstops"]), int(r["missing_cols"])) == \
+               (o["seg_S"], o["seg_N"], o["H_S"], o["H_N"], o["nstops"], o["missing_cols"]), i
+        assert C.close(stats.syn_sites_from_bins(out.syn_num[i]), o["count_syn"], 1e-12), i
+
+
+def test_mixed_batch_runs_every_unit_on_its_own_kernel(gpu):
+    """50-row, 100-row, 300-row and 1 000-row units, coding and not, with and without row subsets, in
+    ONE plan: several launches (buckets), every unit equal to the oracle."""
+    b = scan.Batch(stride_align=128)
+    mats, specs = [], []
+    for i, (n, L, cds) in enumerate([(50, 3000, False), (50, 2997, True), (100, 5000, False), (300, 2000, False),
+                                     (1000, 700, False), (1000, 900, True), (7, 300, False), (64, 1000, True),
+                                     (65, 1000, True), (128, 4000, False), (200, 1500, True), (50, 10000, False)]):
+        p = synth.make_params(n, 0.03)
+        m = synth.synth_alignment(77, i, L, p, coding=cds)
+        if i % 4 == 3:
+            m = synth.inject_symbols(m, 5, 0.002, b"-NRY")
+        mid = b.add_matrix(m)
+        mats.append(m)
+        b.add_unit(mid, cds=cds)
+        specs.append((len(mats) - 1, cds, None))
+        if n >= 50:
+            rows = np.arange(1, n, 2, dtype=np.uint32)
+            b.add_unit(mid, rows=rows, cds=cds)
+            specs.append((len(mats) - 1, cds, rows))
+    bases, table = b.pack()
+    dev = scan.DeviceBuffer(len(bases))
+    dev.upload(bases)
+    plan = scan.Plan(table)
+    assert plan.n_launches >= 5, plan.description
+    assert "scan_tall_kernel" in plan.description and "tw=128" in plan.description and "tw=256" in plan.description
+    plan.run(dev)
+    out = plan.fetch()
+    for i, (mi, cds, rows) in enumerate(specs):
+        _check(out, i, mats[mi], cds=cds, rows=rows)
+    plan.run(dev)                      # the slab is clean again after a fetch: a second run gives the same
+    out2 = plan.fetch()
+    assert (out.results == out2.results).all() and (out.sfs_flat == out2.sfs_flat).all()
+    plan.run(dev)
+    plan.run(dev)                      # two runs without a fetch in between: still one run's worth
+    out3 = plan.fetch()
+    assert (out.results == out3.results).all() and (out.sfs_flat == out3.sfs_flat).all() and (out.syn_num == out3.syn_num).all()
+    plan.close()
+    dev.free()
+
+
+@pytest.mark.parametrize("tw", [64, 128, 256])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 50, 63, 101, 130])
+def test_narrow_tiles_equal_the_oracle(gpu, monkeypatch, tw, n):
+    """every tile width on odd row counts (row groups with and without a last partial step) and lengths
+    that end inside a tile, plain and through a row subset"""
+    monkeypatch.setenv("PFA_FORCE_TW", str(tw))
+    p = synth.make_params(max(n, 2), 0.05)
+    b = scan.Batch(stride_align=16)
+    mats = []
+    for i, L in enumerate((1, 63, 64, 65, 129, 700, 1031)):
+        m = synth.synth_alignment(31 + n, i, L, p)[:n]
+        m = synth.inject_symbols(m, 9, 0.01, b"-NK") if i % 2 else m
+        mats.append(m)
+        mid = b.add_matrix(m)
+        b.add_unit(mid)
+        if n > 2:
+            b.add_unit(mid, rows=np.arange(n - 1, -1, -2, dtype=np.uint32))
+    out = scan.scan_batch(b)
+    k = 0
+    for m in mats:
+        _check(out, k, m)
+        k += 1
+        if n > 2:
+            _check(out, k, m, rows=np.arange(n - 1, -1, -2))
+            k += 1
+
+
+def test_coding_unit_above_2048_rows(gpu):
+    """getvarCDSsites has no row limit (PolyFastA.py:284-315): a 5 000-row coding unit, its per-site H
+    kept in 56 bits, against the oracle — records, SFS, synonymous bins and the S / N positions"""
+    n, L = 5000, 1203
+    p = synth.make_params(n, 0.004)
+    m = synth.synth_alignment(8, 0, L, p, coding=True)
+    m = synth.inject_symbols(m, 3, 0.0004, b"-N")
+    out = scan.scan_matrix(m, cds=True, want_pos=True, want_sn=True)
+    o = c_oracle.scan(m, cds=True, want_sites=True)
+    _check(out, 0, m, cds=True)
+    assert out.var_positions(0).tolist() == np.flatnonzero(o["h_site"]).tolist()
+    assert out.syn_positions(0).tolist() == np.flatnonzero(o["labels"] == 1).tolist()
+    assert out.non_positions(0).tolist() == np.flatnonzero(o["labels"] == 2).tolist()
+    out2 = scan.scan_matrix(m, cds=True)          # the lean instantiation
+    assert (out2.results == out.results).all() and (out2.syn_num == out.syn_num).all()
+
+
+def test_sfs_flag_prints_the_folded_spectrum(gpu, tmp_path):
+    """--sfs (non-default extra): the `sfs` column equals getsfs of the reference on its own example
+    files (G1), NA where getsfs raises IndexError (a variable column with < 2 A/C/G/T alleles)"""
+    g1 = C.load("g1_examples.json")
+    ex = os.path.join(C.GOLDEN, "example_theta_0.01")
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        assert cli.main(["-d", ex, "--sfs"]) == 0
+    lines = buf.getvalue().rstrip("\n").split("\n")
+    assert lines[0] == cli.HEADER_PLAIN + ",sfs"
+    seen = 0
+    for ln in lines[1:]:
+        f = ln.split(",")
+        if f[0] in g1 and f[0].endswith(".fa"):
+            assert [int(x) for x in f[-1].split(";")] == g1[f[0]]["sfs"], f[0]
+            seen += 1
+    assert seen == 10
+    (tmp_path / "gap.fa").write_text(">a\nAC-T\n>b\nACAT\n>c\nACAT\n>d\nAGAT\n")
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        assert cli.main(["-f", str(tmp_path / "gap.fa"), "--sfs", "-s"]) == 0
+    assert buf.getvalue().rstrip("\n").split(",")[-1] == "NA"

@@ -1,20 +1,32 @@
-"""N > 1 host path on CPU: world_size-2 gloo job."""
+"""N > 1 host path on CPU: sharding, launcher, unique-id rendezvous, and a
+world_size-2 gloo job through the product's gather / merge code."""
 import json
 import os
 import socket
 import subprocess
 import sys
+import textwrap
+import threading
+import time
 
 from polyfasta_amd import dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_shard_indices_cover_everything_once():
+def test_shards_cover_everything_once_and_balance():
     for n in (0, 1, 7, 16):
         for world in (1, 2, 3, 8):
             got = sorted(i for r in range(world) for i in dist.shard_indices(n, r, world))
             assert got == list(range(n))
+    # skewed sizes: the greedy split keeps the heaviest rank within one item of the mean
+    sizes = [500_000] * 40 + [20_000_000, 9_000_000, 7_000_000]
+    shards = dist.shard_by_size(sizes, 4)
+    assert sorted(i for s in shards for i in s) == list(range(len(sizes)))
+    loads = [sum(sizes[i] for i in s) for s in shards]
+    assert max(loads) <= 20_000_000          # the 20 MB file alone; round-robin would stack 3 big files on 2 ranks
+    assert max(loads[1:]) - min(loads[1:]) <= 500_000
+    assert all(s == sorted(s) for s in shards)
 
 
 def _free_port():
@@ -33,3 +45,55 @@ def test_two_rank_gloo_gather(tmp_path):
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.load(open(out))
     assert res["ok"] and res["world"] == 2 and res["tmax"] == 2.0 and res["n"] > 23
+
+
+def test_unique_id_rendezvous_file(tmp_path, monkeypatch):
+    """rank 0 publishes, the others wait for a complete file; a reader that starts first still gets it"""
+    monkeypatch.setenv("PFA_RDZV_FILE", str(tmp_path / "id"))
+    blob = bytes(range(128))
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault(1, dist.exchange_unique_id(1, None, 128, timeout=20)))
+    t.start()
+    time.sleep(0.05)
+    assert dist.exchange_unique_id(0, lambda: blob, 128) == blob
+    t.join()
+    assert got[1] == blob
+    # launcher-derived name: identical for all ranks of one launcher
+    monkeypatch.delenv("PFA_RDZV_FILE")
+    monkeypatch.setenv("MASTER_PORT", "29517")
+    assert dist.rendezvous_path() == dist.rendezvous_path() and "29517" in dist.rendezvous_path()
+
+
+def test_spawn_ranks_env_and_failure(tmp_path):
+    """the --gpus launcher: N children with RANK / LOCAL_RANK / WORLD_SIZE, a failing rank fails the job,
+    and (without the rehearsal switch) asking for more GPUs than are visible exits non-zero"""
+    script = tmp_path / "child.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        open(os.path.join(sys.argv[1], "rank" + os.environ["RANK"]), "w").write(
+            ",".join(os.environ[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR")) + "," +
+            str(os.path.dirname(os.environ["PFA_RDZV_FILE"]) != ""))
+        sys.exit(3 if sys.argv[2] == "fail" and os.environ["RANK"] == "1" else 0)
+    """))
+    env_before = dict(os.environ)
+    os.environ["PFA_ALLOW_SHARED_GPU"] = "1"
+    try:
+        assert dist.spawn_ranks(3, [sys.executable, str(script), str(tmp_path), "ok"], timeout=120) == 0
+        for r in range(3):
+            assert open(tmp_path / f"rank{r}").read() == f"{r},{r},3,127.0.0.1,True"
+        assert dist.spawn_ranks(2, [sys.executable, str(script), str(tmp_path), "fail"], timeout=120) == 3
+    finally:
+        os.environ.clear()
+        os.environ.update(env_before)
+    if (dist.visible_gpu_count() or 0) < 64:     # there is no box with 64 GPUs: the launcher must refuse
+        have = dist.visible_gpu_count()
+        if have is not None:
+            assert dist.spawn_ranks(64, [sys.executable, str(script), str(tmp_path), "ok"], timeout=120) == 2
+
+
+def test_cli_gpus_flag_refuses_a_mismatched_launcher(monkeypatch, capsys):
+    from polyfasta_amd import cli
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    assert cli.main(["-f", "x.fa", "--gpus", "4"]) == 2
+    assert "--gpus 4" in capsys.readouterr().err

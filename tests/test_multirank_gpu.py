@@ -1,0 +1,103 @@
+"""The multi-rank path with REAL scans: the CLI as two ranks on the one GPU of
+the test box gives the single-process CSV byte for byte (row order = sorted paths,
+PolyFastA.py:104; population order as typed, :124); the RCCL communicator of the C ABI with one
+rank; the launcher's refusal of more ranks than GPUs."""
+import io
+import os
+import subprocess
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from polyfasta_amd import cli, dist, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _make_dir(tmp_path, n_files=37):
+    d = tmp_path / "aln"
+    d.mkdir()
+    rng = np.random.default_rng(5)
+    for i in range(n_files):
+        n = int(rng.choice([12, 20, 50, 80]))
+        L = int(rng.choice([900, 3000, 9000, 30000])) if i != 5 else 150000      # one heavy file: the split is by size
+        p = synth.make_params(n, 0.02)
+        m = synth.synth_alignment(4200, i, L, p, coding=True)
+        (d / f"g{i:02d}.fa").write_text(synth.to_fasta_text(synth.headers_for(n, 2), m))
+    (d / "zz_not_fasta.fa").write_text("no header here\nACGT\n")
+    (d / "zz_unequal.fa").write_text(">pop1_a\nACGT\n>pop2_b\nACG\n")
+    return d
+
+
+def _single(argv):
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        assert cli.main(argv) == 0
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize("extra", [[], ["--cds", "--jc", "-p", "pop1,pop2"], ["--sfs", "-p", "pop2,nopop,pop1"]])
+def test_two_rank_cli_equals_single_process(gpu, tmp_path, extra):
+    d = _make_dir(tmp_path)
+    argv = ["-d", str(d), "-s"] + extra
+    want = _single(argv)
+    assert want.count("\n") > 37
+    out = tmp_path / "rank0.csv"
+    port = dist._free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_cli_rank_worker.py"), str(out)] + argv,
+                                      env=env, cwd=ROOT, stderr=subprocess.PIPE))
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err.decode()[-3000:]
+    assert open(out).read() == want
+
+
+def test_rccl_comm_one_rank(gpu, tmp_path):
+    """pfa_comm_* on librccl with a world of one: unique id through the rendezvous file, barrier,
+    max-reduction, host-staged all-gather, and the device-side gather of a plan's records."""
+    code = """
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from polyfasta_amd import _lib, dist, scan, synth
+c = dist.RcclComm()
+assert (c.rank, c.world) == (0, 1)
+c.barrier()
+assert c.max_float(2.5) == 2.5
+assert c.all_gather_bytes(b"hello") == [b"hello"]
+p = synth.make_params(20, 0.02)
+b = scan.Batch(stride_align=128)
+for i in range(3):
+    b.add_unit(b.add_matrix(synth.synth_alignment(1, i, 1000, p)))
+bases, table = b.pack()
+dev = scan.DeviceBuffer(len(bases)); dev.upload(bases)
+plan = scan.Plan(table)
+plan.run(dev)
+got = c.all_gather_plan_results(plan)
+out = plan.fetch()
+assert got.shape == (1, 3) and (got[0] == out.results).all() and out.results["seg_sites"].min() > 0
+c.close()
+print("rccl-one-rank-ok")
+""" % ROOT
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", PFA_RDZV_FILE=str(tmp_path / "id"))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "rccl-one-rank-ok" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
+
+
+def test_gpus_flag_fails_loudly_without_enough_gpus(gpu, tmp_path):
+    """`--gpus 4` on a box with fewer GPUs: non-zero exit, a message, no rows (never a silent 1-GPU run)"""
+    have = dist.visible_gpu_count()
+    if have is None or have >= 4:
+        pytest.skip("needs a box with a readable topology and fewer than 4 GPUs")
+    d = _make_dir(tmp_path, n_files=3)
+    p = subprocess.run([sys.executable, "-m", "polyfasta_amd", "-d", str(d), "--gpus", "4"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "--gpus 4" in p.stderr and "g00.fa" not in p.stdout
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0", "--batch", "8"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and '"n_gpus"' not in p.stdout

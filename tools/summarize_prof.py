@@ -5,6 +5,7 @@ gfx950 correction of MI355X_MICROARCH.md §HBM (FETCH_SIZE counts half the bytes
 of a 16-B/lane coalesced stream: x2; WRITE_SIZE is exact), and the bench line
 printed by the profiled command."""
 import csv
+import datetime
 import glob
 import json
 import os
@@ -13,6 +14,8 @@ import sys
 
 tag, name = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import bench  # noqa: E402  (kernel_sources_sha: the bench line reports a traffic figure only for the sources it was taken with)
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -24,13 +27,13 @@ shutil.copyfile(stats, os.path.join(dst, f"{name}_kernel_stats.csv"))
 def counter(kind, cname):
     f = max(glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if r["Counter_Name"] == cname and "pfa::scan_" in r["Kernel_Name"]]
+            if r["Counter_Name"] == cname and "pfa::scan_" in r["Kernel_Name"] and float(r["Counter_Value"]) > 0]
     return vals
 
 
 fetch = counter("pmc_fetch", "FETCH_SIZE")
 write = counter("pmc_write", "WRITE_SIZE")
-bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
+bench_line = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
 kstat = [r for r in csv.DictReader(open(stats)) if "pfa::scan_" in r["Name"]][0]
 fetch_kb, write_kb = sum(fetch) / len(fetch), sum(write) / len(write)
 traffic = 2.0 * fetch_kb * 1024 + write_kb * 1024
@@ -43,10 +46,14 @@ summary = {
     "correction": "HBM bytes = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-B requests of a 16-B/lane stream at 64 B) "
                   "+ WRITE_SIZE x 1024 (exact; calibrated here on pfa::synth_kernel, which writes a known byte count)",
     "traffic_bytes_per_launch": traffic,
-    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-    "workload": bench["config"],
-    "bench_roofline_same_command": bench["roofline"],
+    "algorithmic_bytes_per_launch": bench_line["roofline"]["algorithmic_bytes_per_launch"],
+    "workload": bench_line["config"],
+    "bench_roofline_same_command": bench_line["roofline"],
+    "kernel_sources_sha16": bench.kernel_sources_sha(),
+    "collected": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+    "calibration": "WRITE_SIZE checked on pfa::synth_kernel (writes a known byte count with 16-B-per-lane stores); "
+                   "FETCH_SIZE x 2 per MI355X_MICROARCH.md §HBM (gfx950 tallies the 128-B requests of a 16-B/lane stream at 64 B)",
 }
 json.dump(summary, open(os.path.join(dst, f"{name}_pmc_summary.json"), "w"), indent=1)
-json.dump(bench, open(os.path.join(dst, f"{name}_bench_under_rocprof.json"), "w"), indent=1)
+json.dump(bench_line, open(os.path.join(dst, f"{name}_bench_under_rocprof.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
