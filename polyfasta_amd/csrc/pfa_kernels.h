@@ -46,6 +46,12 @@ __device__ __forceinline__ kernarg_ptr_t kernargs_again() {
   return p;
 }
 
+// the output replica `off` bytes behind the first (ScanArgs::rep_stride)
+template <class T>
+__device__ __forceinline__ T* replica(T* p, uint32_t off) {
+  return reinterpret_cast<T*>(reinterpret_cast<uint8_t*>(p) + off);
+}
+
 // H and allele-presence mask (which of A, C, T, G occur: codon base order) of a variable site,
 // as the coding pass reads them; HT = uint32_t, or unsigned long long for units above 2 048 rows
 template <class HT>
@@ -76,6 +82,14 @@ __device__ inline unsigned long long wave_sum(unsigned long long v) {
 __device__ inline uint32_t quad_sum(uint32_t v) {
   v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
   v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  return v;
+}
+// sum over aligned groups of 4, 8 or 16 lanes (`lps_log` = 2, 3, 4: wave-uniform), every lane of the
+// group gets it (DPP moves only)
+__device__ inline uint32_t group_sum(uint32_t v, uint32_t lps_log) {
+  v = quad_sum(v);
+  if (lps_log >= 3u) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);   // row_half_mirror: the other quad
+  if (lps_log >= 4u) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);   // row_mirror: the other half row
   return v;
 }
 // Workgroups are ONE wavefront: "synchronising" it only means ordering its LDS traffic (lanes
@@ -163,7 +177,9 @@ struct CodonPass {
   unsigned long long my_same;     // same_annot[c]
   uint32_t my_cinfo;              // synonymous-neighbour count | stop << 7, read with ds_bpermute
   uint32_t my_slut[3];            // the three 256-byte planes of SingleLut, one word per lane each
-  uint32_t* synhist;              // LDS: PFA_SYN_BINS bins of synonymous-site numerators by codon count
+  uint32_t* synhist;              // LDS: kSynLdsBins bins of synonymous-site numerators, codon counts 2 .. kSynLdsBins + 1
+  uint32_t unit;
+  uint32_t rep_off;               // byte offset of this chunk's output replica (ScanArgs::rep_stride)
   unsigned long long* syn_bm;     // optional per-site S / N bitmaps
   unsigned long long* non_bm;
   uint32_t tile_off;
@@ -179,8 +195,10 @@ struct CodonPass {
   uint32_t pv[2];                 // the variable position of a `single` column
   uint32_t site0;
 
-  __device__ void init(uint32_t lane_, uint32_t* synhist_, const ScanArgs& A, const pfa_desc& D) {
+  __device__ void init(uint32_t lane_, uint32_t unit_, uint32_t* synhist_, const ScanArgs& A, const pfa_desc& D) {
     lane = lane_;
+    unit = unit_;
+    rep_off = (blockIdx.y & A.rep_mask) * A.rep_stride;
     synhist = synhist_;
     syn_bm = A.syn_bm;
     non_bm = A.non_bm;
@@ -195,6 +213,14 @@ struct CodonPass {
   // table entry of another lane (the LDS crossbar, no LDS memory); every lane must be enabled
   __device__ static uint32_t lane_lookup(uint32_t from_lane, uint32_t mine) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)mine);
+  }
+
+  // synonymous-site numerator t3 of a column with k distinct clean codons (PolyFastA.py:307): columns
+  // with one codon are summed in a register, 2 .. kSynLdsBins + 1 in LDS, more (hardly ever) in memory
+  __device__ void syn_add(uint32_t k, uint32_t t3) {
+    if (k == 1u) acc_syn1 += t3;
+    else if (k - 2u < kSynLdsBins) atomicAdd(&synhist[k - 2u], t3);
+    else atomicAdd(replica(kernargs_again()->syn_num, rep_off) + (uint64_t)unit * PFA_SYN_BINS + k, t3);
   }
 
   __device__ void mark_site(bool is_s, int rel_site) const {
@@ -256,8 +282,7 @@ struct CodonPass {
     const bool stop = (M & kStop) != 0ull;
     const uint32_t labels = classify_uniform(M & ~kStop, lane, my_info, my_same);
     if (lane == 0u) {
-      if (k == 1u) acc_syn1 += t3;
-      else atomicAdd(&synhist[k], t3);
+      syn_add(k, t3);
       acc_stops += stop ? 1u : 0u;
 #pragma unroll
       for (uint32_t p = 0; p < 3u; ++p) {
@@ -363,8 +388,7 @@ struct CodonPass {
       if (!valid) return;
       if (k == 0u) { acc_missing += 1u; return; }
       const uint32_t t3 = v & 0x1Fu;
-      if (k == 1u) acc_syn1 += t3;
-      else atomicAdd(&synhist[k], t3);
+      syn_add(k, t3);
       acc_stops += (v >> 5) & 1u;
       const bool is_s = (v & 0x40u) != 0u, is_n = (v & 0x80u) != 0u;
       const auto hs = hv.h;
@@ -397,8 +421,8 @@ struct CodonPass {
     acc_HS = wave_sum(acc_HS);
     acc_HN = wave_sum(acc_HN);
     const kernarg_ptr_t K = kernargs_again();
-    pfa_result* const R = K->results + unit;
-    uint32_t* const syn_num_unit = K->syn_num + (uint64_t)unit * PFA_SYN_BINS;
+    pfa_result* const R = replica(K->results, rep_off) + unit;
+    uint32_t* const syn_num_unit = replica(K->syn_num, rep_off) + (uint64_t)unit * PFA_SYN_BINS;
     if (lane == 0u) {
       if (acc_segS) atomicAdd(&R->seg_S, acc_segS);
       if (acc_segN) atomicAdd(&R->seg_N, acc_segN);
@@ -409,9 +433,9 @@ struct CodonPass {
       if (acc_syn1) atomicAdd(&syn_num_unit[1], acc_syn1);
     }
     wave_lds_sync();
-    for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) {
-      const uint32_t v = synhist[i];
-      if (v) atomicAdd(&syn_num_unit[i], v);
+    if (lane < kSynLdsBins) {
+      const uint32_t v = synhist[lane];
+      if (v) atomicAdd(&syn_num_unit[lane + 2u], v);
     }
   }
 };

@@ -27,28 +27,33 @@ struct Geo {
 };
 
 struct LdsLayout {
-  uint32_t tile, list, hist, rowmap, hsite, carry, synhist, total;
+  uint32_t tile, list, hist, rowmap, synhist, total;
 };
 
 PFA_HD inline uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
 
-// scan_kernel: `n_max` = most rows of any unit of the launch, `tw` = its tile width
-PFA_HD inline LdsLayout lds_layout(uint32_t tw, uint32_t n_max, bool cds, bool rowmap) {
+// bins of synonymous-site numerators kept in LDS: codon columns with 2 .. kSynLdsBins + 1 distinct
+// clean codons (one codon: a register; more: global atomics, hardly ever)
+static constexpr uint32_t kSynLdsBins = 32u;
+
+// scan_kernel: `n_max` = most rows of any unit of the launch, `tw` = its tile width; `mapped`: the
+// instantiation serves row-index lists.
+//   tile   exactly N rows (lanes of the last DMA instruction beyond row N-1 are masked off; narrow
+//          tiles are read G rows at a time, the last step by the lane groups that still have a row)
+//   list   the tile's variable sites, tw entries: `site | XOR byte << 8` from the compaction, turned
+//          by tier 2 (coding launches) into the site's `H | allele mask`: 16 bits (H < 4096 | mask <<
+//          12) when no unit has more than 64 rows, else 32 (H | mask << 24).  Coding launches keep two
+//          more entries in FRONT of it: the last two sites of the previous tile.
+PFA_HD inline LdsLayout lds_layout(uint32_t tw, uint32_t n_max, bool cds, bool mapped) {
   const uint32_t n = n_max ? n_max : 1u;
+  const uint32_t entry = (cds && n > 64u) ? 4u : 2u;
   LdsLayout o;
   o.tile = 0;
-  // exactly N rows: lanes of the last DMA instruction beyond row N-1 are masked off.  Narrow tiles
-  // are read G rows at a time, the last step by the lane groups that still have a row.
-  o.list = round16(n * tw);
-  o.hist = o.list + 2u * tw;   // list: the tile's variable sites, tw u16 entries (site | XOR byte << 8)
+  o.list = round16(n * tw) + (cds ? 16u : 0u);
+  o.hist = o.list + entry * tw;
   o.rowmap = o.hist + round16((n / 2u) * 4u + 4u);
-  // hsite[s]: H and allele mask of variable site s (written by tier 2; entries of other sites are stale
-  // and never used): 16 bits (H < 4096 | mask << 12) when no unit has more than 64 rows, else 32
-  // (H | mask << 24); hsite[-2], hsite[-1]: the last two sites of the previous tile
-  o.hsite = o.rowmap + (rowmap ? round16(n * 4u) : 0u) + (cds ? 16u : 0u);
-  o.carry = o.hsite + (cds ? tw * (n <= 64u ? 2u : 4u) : 0u);
-  o.synhist = o.carry + (cds ? round16(2u * n) : 0u);   // carry: last two columns of the previous tile, per row
-  o.total = o.synhist + (cds ? round16(PFA_SYN_BINS * 4u) : 0u);
+  o.synhist = o.rowmap + (mapped ? round16(n * 4u) : 0u);   // rowmap: byte offsets of the unit's rows (--pops)
+  o.total = o.synhist + (cds ? kSynLdsBins * 4u : 0u);
   return o;
 }
 
@@ -69,6 +74,12 @@ struct ScanArgs {
   uint32_t rows_per_chunk;  // tall kernel: rows staged per pass (multiple of 4, 8..64)
   uint32_t max_slots;       // tall kernel: count-table slots per tile (variable sites beyond take the column path)
   uint32_t hist_bins;       // tall kernel: SFS bins kept in LDS (higher bins go straight to global atomics)
+  // Plans with few units but many chunks per unit keep `rep_mask + 1` replicas of their outputs
+  // (records | sfs | syn_num, `rep_stride` bytes apart): chunk c adds into replica c & rep_mask, the
+  // fetch sums them.  Otherwise thousands of wavefronts would queue on the atomics of a handful of
+  // cache lines (measured: BASELINE config 3 as one launch, 24 -> 66 us when 4x more wavefronts shared it).
+  uint32_t rep_mask;
+  uint32_t rep_stride;
 };
 
 struct TallLayout {
@@ -91,7 +102,7 @@ PFA_HD inline TallLayout tall_layout(uint32_t rows_per_chunk, uint32_t max_slots
   o.hsite = o.hist + round16(hist_bins * 4u + 4u) + (cds ? 16u : 0u);
   o.synhist = o.hsite + (cds ? 256u * hbytes : 0u);
   // codon slots: the codon sets of up to 8 joint columns of the tile, tracked chunk by chunk
-  o.cslots = o.synhist + (cds ? round16(PFA_SYN_BINS * 4u) : 0u);
+  o.cslots = o.synhist + (cds ? kSynLdsBins * 4u : 0u);
   o.total = o.cslots + (cds ? 32u + 64u : 0u);
   return o;
 }

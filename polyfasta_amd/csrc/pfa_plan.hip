@@ -47,6 +47,25 @@ __global__ void __launch_bounds__(256) slab_to_host_kernel(uint4* __restrict__ s
   }
 }
 
+// The same for a plan with output replicas (ScanArgs::rep_mask): the replicas are summed on the way
+// — 64-bit words of the records section that hold H, H_S, H_N (words 0-2 of the 7 of a record) as
+// 64-bit integers, everything else as pairs of 32-bit counters — and cleared.  dst == src sums in place.
+__global__ void __launch_bounds__(256) sum_replicas_kernel(unsigned long long* __restrict__ src, unsigned long long* dst, size_t n64,
+                                                           uint32_t replicas, size_t stride64, size_t n_rec_words) {
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n64; w += (size_t)gridDim.x * blockDim.x) {
+    const bool wide = w < n_rec_words && (w % 7u) < 3u;
+    unsigned long long acc = src[w];
+    src[w] = 0ull;
+    for (uint32_t r = 1; r < replicas; ++r) {
+      const unsigned long long v = src[w + r * stride64];
+      src[w + r * stride64] = 0ull;
+      acc = wide ? acc + v
+                 : (unsigned long long)((uint32_t)acc + (uint32_t)v) | (unsigned long long)((uint32_t)(acc >> 32) + (uint32_t)(v >> 32)) << 32;
+    }
+    dst[w] = acc;
+  }
+}
+
 static constexpr uint32_t kLdsPerCu = 160u * 1024u;
 static constexpr uint32_t kTallRows = 48u;      // rows per chunk of the row-chunked kernel (upper bound)
 static constexpr uint32_t kTallSlots = 64u;     // its count-table slots per tile (measured: 64 6.03, 96 5.68 TB/s at N = 100)
@@ -148,7 +167,9 @@ struct pfa_plan {
   uint8_t* h_slab_dev = nullptr;   // the device's address of h_slab
   bool slab_clean = false;         // the device slab holds zeros
   bool host_valid = false;         // h_slab holds the outputs of the last run
-  size_t slab_bytes = 0, off_sfs = 0, off_syn = 0;
+  size_t slab_bytes = 0, off_sfs = 0, off_syn = 0;   // one replica
+  uint32_t replicas = 1;           // copies of the slab that the chunks of a unit spread their atomics over
+  bool summed = true;              // replica 0 holds the sum, the others zeros
   pfa_result* d_results = nullptr;
   uint32_t* d_sfs = nullptr;
   uint32_t* d_syn = nullptr;
@@ -419,6 +440,10 @@ static std::string describe(const pfa_plan* p) {
                (int)b.cfg.cds, (int)(b.cfg.mapped || b.cfg.bitmaps), (int)b.cfg.bitmaps, b.cfg.tw, b.cfg.n_units, b.n_max, b.cfg.lds_bytes, b.tiles_per_chunk);
     s += buf;
   }
+  if (p->replicas > 1u) {
+    snprintf(buf, sizeof buf, " | %u output replicas", p->replicas);
+    s += buf;
+  }
   return s;
 }
 
@@ -520,6 +545,13 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
     }
     std::stable_sort(p->buckets.begin(), p->buckets.end(),
                      [](const pfa::Bucket& a, const pfa::Bucket& b) { return a.bytes > b.bytes; });
+    // few units, many chunks per unit: spread each unit's atomics over replicas of the slab (about
+    // 24 wavefronts per replica and unit)
+    uint32_t max_chunks = 1;
+    for (const pfa::Bucket& b : p->buckets) max_chunks = std::max(max_chunks, b.cfg.n_chunks);
+    while (p->replicas < 32u && max_chunks / p->replicas > 24u && (uint64_t)n_desc * p->replicas * 2u <= 4096u) p->replicas *= 2u;
+    if (getenv("PFA_REPLICAS")) p->replicas = std::min(64u, std::max(1u, pfa::env_u32("PFA_REPLICAS", 1u)));   // timing experiments (a power of two)
+    if (p->replicas & (p->replicas - 1u)) p->replicas = 1u;
     p->description = pfa::describe(p);
   } catch (const std::bad_alloc&) {
     delete p;
@@ -561,8 +593,8 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
     p->off_sfs = up((size_t)n_desc * sizeof(pfa_result));
     p->off_syn = p->off_sfs + up(std::max<size_t>(16, sfs_words * sizeof(uint32_t)));
     p->slab_bytes = p->off_syn + (any_cds ? up((size_t)n_desc * PFA_SYN_BINS * sizeof(uint32_t)) : 0);
-    PLAN_HIP(pfa::g_pool.take(false, p->slab_bytes, (void**)&p->d_slab, &p->cap_slab));
-    PLAN_HIP(hipMemsetAsync(p->d_slab, 0, p->slab_bytes, st));
+    PLAN_HIP(pfa::g_pool.take(false, p->slab_bytes * p->replicas, (void**)&p->d_slab, &p->cap_slab));
+    PLAN_HIP(hipMemsetAsync(p->d_slab, 0, p->slab_bytes * p->replicas, st));
     p->slab_clean = true;
     PLAN_HIP(pfa::g_pool.take(true, p->slab_bytes, (void**)&p->h_slab, &p->cap_hslab));
     PLAN_HIP(hipHostGetDevicePointer((void**)&p->h_slab_dev, p->h_slab, 0));
@@ -596,9 +628,10 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   if (!p || !d_bases) { pfa::set_error("pfa_plan_run: NULL argument"); return PFA_ERR_ARG; }
   if (variant != 0 && variant != 2) { pfa::set_error("pfa_plan_run: variant %d (0 = default, 2 = default cache policy)", variant); return PFA_ERR_ARG; }
   hipStream_t st = pfa::ctx().stream;
-  if (!p->slab_clean) PFA_HIP(hipMemsetAsync(p->d_slab, 0, p->slab_bytes, st));
+  if (!p->slab_clean) PFA_HIP(hipMemsetAsync(p->d_slab, 0, p->slab_bytes * p->replicas, st));
   p->slab_clean = false;
   p->host_valid = false;
+  p->summed = p->replicas == 1u;
   if (p->d_syn_bm) {  // S / N bitmaps are built with atomicOr: clear them every run
     const size_t nb = std::max<size_t>(1, p->n_tiles_total) * 4u * sizeof(uint64_t);
     PFA_HIP(hipMemsetAsync(p->d_syn_bm, 0, nb, st));
@@ -628,6 +661,8 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
     a.rows_per_chunk = b.rows_per_chunk;
     a.max_slots = b.max_slots;
     a.hist_bins = b.hist_bins;
+    a.rep_mask = p->replicas - 1u;
+    a.rep_stride = (uint32_t)p->slab_bytes;
     pfa::LaunchCfg c = b.cfg;
     // the default-cache-policy variant exists for the 256-site lean / general instantiations (A/B)
     c.stage = (variant == 2 && c.tw == 256u && !c.wide) ? 0 : 2;
@@ -667,14 +702,23 @@ int pfa_plan_fetch(pfa_plan* p, pfa_result* results, uint32_t* sfs, uint32_t* sy
     if (!p->host_valid) {
       // one device-side copy into pinned memory (which also clears the slab for the next run),
       // then plain memcpy into the caller's (pageable) arrays
-      const size_t n16 = p->slab_bytes / 16u;   // slab sections are padded to 256 bytes
-      const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255u) / 256u, 1024u);
-      hipLaunchKernelGGL(pfa::slab_to_host_kernel, dim3(blocks), dim3(256), 0, st,
-                         reinterpret_cast<uint4*>(p->d_slab), reinterpret_cast<uint4*>(p->h_slab_dev), n16);
+      if (p->replicas == 1u) {
+        const size_t n16 = p->slab_bytes / 16u;   // slab sections are padded to 256 bytes
+        const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255u) / 256u, 1024u);
+        hipLaunchKernelGGL(pfa::slab_to_host_kernel, dim3(blocks), dim3(256), 0, st,
+                           reinterpret_cast<uint4*>(p->d_slab), reinterpret_cast<uint4*>(p->h_slab_dev), n16);
+      } else {
+        const size_t n64 = p->slab_bytes / 8u;
+        const unsigned blocks = (unsigned)std::min<size_t>((n64 + 255u) / 256u, 1024u);
+        hipLaunchKernelGGL(pfa::sum_replicas_kernel, dim3(blocks), dim3(256), 0, st,
+                           reinterpret_cast<unsigned long long*>(p->d_slab), reinterpret_cast<unsigned long long*>(p->h_slab_dev), n64,
+                           p->replicas, n64, (size_t)p->n_desc * 7u);
+      }
       PFA_HIP(hipGetLastError());
       PFA_HIP(hipStreamSynchronize(st));
       p->host_valid = true;
       p->slab_clean = true;
+      p->summed = true;
     }
     if (results) memcpy(results, p->h_slab, (size_t)p->n_desc * sizeof(pfa_result));
     if (sfs && p->sfs_words) memcpy(sfs, p->h_slab + p->off_sfs, p->sfs_words * sizeof(uint32_t));
@@ -698,6 +742,15 @@ int pfa_plan_results_dev(pfa_plan* p, void** d_results, size_t* bytes) {
   PFA_NEED_INIT();
   if (!p || !d_results || !bytes) { pfa::set_error("pfa_plan_results_dev: NULL argument"); return PFA_ERR_ARG; }
   if (p->host_valid) { pfa::set_error("pfa_plan_results_dev: the records have been fetched (the device slab is cleared by a fetch)"); return PFA_ERR_ARG; }
+  if (!p->summed) {   // plans with output replicas: sum them into the first, in place, behind the scans
+    const size_t n64 = p->slab_bytes / 8u;
+    const unsigned blocks = (unsigned)std::min<size_t>((n64 + 255u) / 256u, 1024u);
+    hipLaunchKernelGGL(pfa::sum_replicas_kernel, dim3(blocks), dim3(256), 0, pfa::ctx().stream,
+                       reinterpret_cast<unsigned long long*>(p->d_slab), reinterpret_cast<unsigned long long*>(p->d_slab), n64,
+                       p->replicas, n64, (size_t)p->n_desc * 7u);
+    PFA_HIP(hipGetLastError());
+    p->summed = true;
+  }
   *d_results = p->d_results;
   *bytes = (size_t)p->n_desc * sizeof(pfa_result);
   return PFA_OK;

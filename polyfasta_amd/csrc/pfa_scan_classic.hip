@@ -45,20 +45,20 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
 
   const LdsLayout lo = lds_layout(TW, A.n_max, HAS_CDS, MAPPED);
   uint8_t* const tile8 = lds + lo.tile;
-  uint16_t* const list = reinterpret_cast<uint16_t*>(lds + lo.list);
+  // the tile's variable sites; wide entries when a coding launch holds units above 64 rows (pfa_layout.h)
+  uint16_t* const list16 = reinterpret_cast<uint16_t*>(lds + lo.list);
+  uint32_t* const list32 = reinterpret_cast<uint32_t*>(lds + lo.list);
+  const bool wide_list = HAS_CDS && A.n_max > 64u;
   uint32_t* const hist = reinterpret_cast<uint32_t*>(lds + lo.hist);
   uint32_t* const rowmap = reinterpret_cast<uint32_t*>(lds + lo.rowmap);
-  uint32_t* const hsite32 = reinterpret_cast<uint32_t*>(lds + lo.hsite);
-  uint16_t* const hsite16 = reinterpret_cast<uint16_t*>(lds + lo.hsite);
-  const bool h16 = A.n_max <= 64u;
-  // H and allele mask of a variable site (tile-relative index, -2 and -1: previous tile)
-  auto hsite_get = [&](int rel) -> HMask<uint32_t> {
-    if (h16) { const uint32_t v = hsite16[rel]; return {v & 0xFFFu, v >> 12}; }
-    const uint32_t v = hsite32[rel];
+  uint32_t* const synhist = reinterpret_cast<uint32_t*>(lds + lo.synhist);
+  // entry i of the list once tier 2 has replaced it by the site's H and allele mask; -2, -1: the last
+  // two sites of the previous tile
+  auto list_hmask = [&](int i) -> HMask<uint32_t> {
+    if (!wide_list) { const uint32_t v = list16[i]; return {v & 0xFFFu, v >> 12}; }
+    const uint32_t v = list32[i];
     return {v & 0xFFFFFFu, v >> 24};
   };
-  uint8_t* const carry = lds + lo.carry;
-  uint32_t* const synhist = reinterpret_cast<uint32_t*>(lds + lo.synhist);
 
   const uint32_t nbins = N / 2u;
   const bool mapped = MAPPED && D.row_idx_off != PFA_NO_ROW_IDX;   // population subset: rows through an index list
@@ -66,15 +66,14 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     // the row's byte offset in the matrix, in 16-byte units (plans keep matrices below 64 GB)
     for (uint32_t i = lane; i < N; i += 64u) rowmap[i] = A.row_idx[D.row_idx_off + i] * (D.row_stride >> 4);
   for (uint32_t i = lane; i < nbins; i += 64u) hist[i] = 0u;
-  if (cds)
-    for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) synhist[i] = 0u;
+  if (cds && lane < kSynLdsBins) synhist[lane] = 0u;
   wave_lds_sync();
 
   // per-lane partial sums of this chunk
   uint32_t acc_S = 0u, acc_bad = 0u;
   unsigned long long acc_H = 0ull;
   CodonPass<BITMAPS> cp;
-  if constexpr (HAS_CDS) cp.init(lane, synhist, A, D);
+  if constexpr (HAS_CDS) cp.init(lane, unit, synhist, A, D);
 
   const uint8_t* const mat = A.bases + D.base_off;
   const uint32_t NN = N * N;
@@ -97,14 +96,25 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       if (rr < N % G::RPI)
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
     } else {
+      // The row offsets come out of LDS eight instructions at a time: the compiler keeps every LDS
+      // read behind the LDS-DMA issued before it (both touch LDS), so reading them one by one would
+      // put an LDS round trip in front of every DMA instruction.
       const uint8_t* const base = mat + col;
-      uint32_t g = 0;
-      for (; g < n_full; ++g)
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + ((uint64_t)rowmap[g * G::RPI + rr] << 4)),
-                                         (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
-      if (rr < N % G::RPI)
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + ((uint64_t)rowmap[g * G::RPI + rr] << 4)),
-                                         (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
+      const uint32_t n_inst = n_full + (N % G::RPI ? 1u : 0u);
+      for (uint32_t g0 = 0; g0 < n_inst; g0 += 8u) {
+        uint32_t off16[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+          const uint32_t r = (g0 + k) * G::RPI + rr;
+          off16[k] = rowmap[r < N ? r : 0u];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+          const uint32_t g = g0 + k;
+          if (g < n_full || (g == n_full && rr < N % G::RPI))
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + ((uint64_t)off16[k] << 4)), (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
+        }
+      }
     }
   };
   // The tile of iteration t+1 is requested as soon as iteration t has read the last byte it needs
@@ -148,12 +158,19 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
 
     // ---------------- compact the variable sites of the tile
     uint32_t P = 0u;
+    uint32_t idx4 = 0u;   // list positions of this lane's variable sites, one byte per site (coding pass)
 #pragma unroll
     for (uint32_t b = 0; b < 4u; ++b) {
       const uint32_t off = 4u * jl + b;
       const bool pb = ((vd >> (8u * b)) & 0xFFu) != 0u && off < lim && rg == 0u;
       const uint64_t m = __ballot(pb);
-      if (pb) list[P + mbcnt64(m)] = uint16_t(off | ((vd >> (8u * b)) & 0xFFu) << 8);
+      if (pb) {
+        const uint32_t i = P + mbcnt64(m);
+        const uint32_t ent = off | ((vd >> (8u * b)) & 0xFFu) << 8;
+        if (wide_list) list32[i] = ent;
+        else list16[i] = uint16_t(ent);
+        if constexpr (HAS_CDS) idx4 |= i << (8u * b);
+      }
       if constexpr (BITMAPS)
         if (A.var_bm != nullptr && lane == 0u) A.var_bm[(uint64_t)(D.tile_off + tile) * 4u + b] = m;
       P += (uint32_t)__popcll(m);
@@ -163,93 +180,114 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     wave_lds_sync();
 
     // ---------------- tier 2: exact allele counts of the variable sites
-    // 4 lanes per site walk its column.  Fast path: x = the byte of row 0, y = x ^ (XOR byte of
-    // the site); when every row holds x or y the site has exactly these two alleles (2 compares
-    // per byte).  Otherwise (3+ alleles, ~1 % of variable sites) the column is walked again
-    // with six counters, and any byte outside A C G T - N takes the exact generic path.
-    const uint32_t slot = lane >> 2, ph = lane & 3u;
-    for (uint32_t p0 = 0; p0 < P; p0 += 16u) {
-      const uint32_t idx = p0 + slot;
-      const bool act = idx < P;
-      const uint32_t ent = list[act ? idx : 0u];
-      const uint32_t s = ent & 0xFFu;
-      const uint8_t* colp = tile8 + s;
-      const uint32_t x = colp[0], y = x ^ (ent >> 8);
-      uint32_t c1 = 0, c2 = 0;
+    // LPS = 4 lanes per site walk its column (8 or 16 lanes for tiles with few variable sites were
+    // measured: no gain, the walk is bound by LDS bank conflicts — every row of a column sits in the
+    // same bank).  Fast path: x = the byte of row 0, y = x ^ (XOR byte of the
+    // site); when every row holds x or y the site has exactly these two alleles (2 compares per
+    // byte).  Otherwise (3+ alleles, ~1 % of variable sites) the column is walked again with six
+    // counters, and any byte outside A C G T - N takes the exact generic path.
+    auto tier2 = [&](auto lps_tag) {
+      constexpr uint32_t LPS = decltype(lps_tag)::value, SPI = 64u / LPS;   // lanes per site, sites per pass
+      constexpr uint32_t lps_log = LPS == 4u ? 2u : LPS == 8u ? 3u : 4u;
+      const uint32_t slot = lane / LPS, ph = lane % LPS;
+      for (uint32_t p0 = 0; p0 < P; p0 += SPI) {
+        const uint32_t idx = p0 + slot;
+        const bool act = idx < P;
+        const uint32_t ent = wide_list ? list32[act ? idx : 0u] : (uint32_t)list16[act ? idx : 0u];
+        const uint32_t s = ent & 0xFFu;
+        const uint8_t* colp = tile8 + s;
+        const uint32_t x = colp[0], y = x ^ ((ent >> 8) & 0xFFu);
+        uint32_t c1 = 0, c2 = 0;
 #pragma unroll 4
-      for (uint32_t r = ph; r < N; r += 4u) {
-        const uint32_t v = colp[r * TW];
-        c1 += (v == x);
-        c2 += (v == y);
-      }
-      c1 = quad_sum(c1);
-      c2 = quad_sum(c2);
-      const bool xc = base_clean(x), yc = base_clean(y);
-      uint32_t sumsq = c1 * c1 + c2 * c2;
-      uint32_t second = (xc && yc) ? umin(c1, c2) : 0u;   // second-largest A/C/G/T count (PolyFastA.py:279-281)
-      uint32_t pres = (xc ? 1u << base_code(x) : 0u) | (yc ? 1u << base_code(y) : 0u);   // which of A, C, T, G occur
-      const bool multi = act && c1 + c2 != N;   // the same in all 4 lanes of the quad
-      if (__any(multi)) {
-        if (multi) {
-          uint32_t cA = 0, cC = 0, cG = 0, cT = 0, cGap = 0, cNn = 0;
-#pragma unroll 4
-          for (uint32_t r = ph; r < N; r += 4u) {
-            const uint32_t v = colp[r * TW];
-            cA += (v == 'A');
-            cC += (v == 'C');
-            cG += (v == 'G');
-            cT += (v == 'T');
-            cGap += (v == '-');
-            cNn += (v == 'N');
-          }
-          cA = quad_sum(cA);
-          cC = quad_sum(cC);
-          cG = quad_sum(cG);
-          cT = quad_sum(cT);
-          cGap = quad_sum(cGap);
-          cNn = quad_sum(cNn);
-          sumsq = cA * cA + cC * cC + cG * cG + cT * cT + cGap * cGap + cNn * cNn;
-          const uint32_t n_other = N - (cA + cC + cG + cT + cGap + cNn);
-          if (n_other != 0u) {
-            // exact path for any other byte value: sum over such rows i of #{j : x_j == x_i}
-            uint32_t extra = 0u;
-            for (uint32_t i = ph; i < N; i += 4u) {
-              const uint32_t xi = colp[i * TW];
-              const bool six = xi == 'A' || xi == 'C' || xi == 'G' || xi == 'T' || xi == '-' || xi == 'N';
-              if (!six) {
-                uint32_t cnt = 0u;
-                for (uint32_t j = 0; j < N; ++j) cnt += (colp[j * TW] == xi);
-                extra += cnt;
-              }
+        for (uint32_t r = ph; r < N; r += LPS) {
+          const uint32_t v = colp[r * TW];
+          c1 += (v == x);
+          c2 += (v == y);
+        }
+        c1 = group_sum(c1, lps_log);
+        c2 = group_sum(c2, lps_log);
+        const bool xc = base_clean(x), yc = base_clean(y);
+        uint32_t sumsq = c1 * c1 + c2 * c2;
+        uint32_t second = (xc && yc) ? umin(c1, c2) : 0u;   // second-largest A/C/G/T count (PolyFastA.py:279-281)
+        uint32_t pres = (xc ? 1u << base_code(x) : 0u) | (yc ? 1u << base_code(y) : 0u);   // which of A, C, T, G occur
+        const bool multi = act && c1 + c2 != N;   // the same in all lanes of the site's group
+        if (__any(multi)) {
+          if (multi) {
+            uint32_t cA = 0, cC = 0, cG = 0, cT = 0, cGap = 0, cNn = 0;
+#pragma unroll 2
+            for (uint32_t r = ph; r < N; r += LPS) {
+              const uint32_t v = colp[r * TW];
+              cA += (v == 'A');
+              cC += (v == 'C');
+              cG += (v == 'G');
+              cT += (v == 'T');
+              cGap += (v == '-');
+              cNn += (v == 'N');
             }
-            sumsq += quad_sum(extra);
+            cA = group_sum(cA, lps_log);
+            cC = group_sum(cC, lps_log);
+            cG = group_sum(cG, lps_log);
+            cT = group_sum(cT, lps_log);
+            cGap = group_sum(cGap, lps_log);
+            cNn = group_sum(cNn, lps_log);
+            sumsq = cA * cA + cC * cC + cG * cG + cT * cT + cGap * cGap + cNn * cNn;
+            const uint32_t n_other = N - (cA + cC + cG + cT + cGap + cNn);
+            if (n_other != 0u) {
+              // exact path for any other byte value: sum over such rows i of #{j : x_j == x_i}
+              uint32_t extra = 0u;
+              for (uint32_t i = ph; i < N; i += LPS) {
+                const uint32_t xi = colp[i * TW];
+                const bool six = xi == 'A' || xi == 'C' || xi == 'G' || xi == 'T' || xi == '-' || xi == 'N';
+                if (!six) {
+                  uint32_t cnt = 0u;
+                  for (uint32_t j = 0; j < N; ++j) cnt += (colp[j * TW] == xi);
+                  extra += cnt;
+                }
+              }
+              sumsq += group_sum(extra, lps_log);
+            }
+            const uint32_t hi1 = umax(cA, cC), lo1 = umin(cA, cC), hi2 = umax(cG, cT), lo2 = umin(cG, cT);
+            second = umax(umin(hi1, hi2), umax(lo1, lo2));
+            pres = (cA ? 1u : 0u) | (cC ? 2u : 0u) | (cT ? 4u : 0u) | (cG ? 8u : 0u);
           }
-          const uint32_t hi1 = umax(cA, cC), lo1 = umin(cA, cC), hi2 = umax(cG, cT), lo2 = umin(cG, cT);
-          second = umax(umin(hi1, hi2), umax(lo1, lo2));
-          pres = (cA ? 1u : 0u) | (cC ? 2u : 0u) | (cT ? 4u : 0u) | (cG ? 8u : 0u);
+        }
+        if (act && ph == 0u) {
+          const uint32_t hs = NN - sumsq;
+          acc_H += hs;
+          if (cds) {   // the list entry becomes the site's H + which of A, C, T, G occur there (codon base order)
+            if (wide_list) list32[idx] = hs | pres << 24;
+            else list16[idx] = uint16_t(hs | pres << 12);
+          }
+          if (second == 0u) acc_bad += 1u;
+          else atomicAdd(&hist[second - 1u], 1u);
         }
       }
-      if (act && ph == 0u) {
-        const uint32_t hs = NN - sumsq;
-        acc_H += hs;
-        if (cds) {   // H of the site + which of A, C, T, G occur there (codon base order)
-          if (h16) hsite16[s] = uint16_t(hs | pres << 12);
-          else hsite32[s] = hs | pres << 24;
-        }
-        if (second == 0u) acc_bad += 1u;
-        else atomicAdd(&hist[second - 1u], 1u);
-      }
-    }
+    };
+    tier2(std::integral_constant<uint32_t, 4u>{});
 
     // ---------------- coding sequences: the codon columns that END in this tile (CodonPass)
     if (cds) {
-      wave_lds_sync();   // tier 2's hsite entries are visible
+      wave_lds_sync();   // tier 2's H | mask entries are visible
       cp.window(va, vd, site0, lim);
-      // columns with two or three variable positions: one row per lane out of the LDS tile; the
-      // one or two sites a codon reaches back into the previous tile come from `carry`
+      // H and allele mask of a variable site (tile-relative, -2 / -1: previous tile) through the list
+      // position its owner lane noted: of any site for a wave-uniform `rel` ...
+      auto hget_uniform = [&](int rel) -> HMask<uint32_t> {
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)idx4, (rel < 0 ? 0 : rel) >> 2);
+        return list_hmask(rel < 0 ? rel : (int)((w >> (8u * ((uint32_t)rel & 3u))) & 0xFFu));
+      };
+      // ... and, per lane, of the sites of this lane and the one before it (every lane active)
+      const unsigned long long idx8 = (unsigned long long)wave_shr1(idx4) | (unsigned long long)idx4 << 32;
+      auto hget_lane = [&](int rel) -> HMask<uint32_t> {
+        const uint32_t k = (uint32_t)(rel - (4 * (int)lane - 4)) & 7u;
+        return list_hmask(rel < 0 ? rel : (int)((uint32_t)(idx8 >> (8u * k)) & 0xFFu));
+      };
+      // columns with two or three variable positions: one row per lane out of the LDS tile; the one or
+      // two sites a codon reaches back into the previous tile are read from memory (a chunk starts on a
+      // codon boundary, so they belong to the unit; rare)
       auto cell = [&](uint32_t r, int rel) -> uint32_t {
-        const uint8_t* q = rel < 0 ? carry + 2u * r + (uint32_t)(2 + rel) : tile8 + r * TW + (uint32_t)rel;
-        return *q;
+        if (rel >= 0) return tile8[r * TW + (uint32_t)rel];
+        const uint64_t row = mapped ? (uint64_t)kernargs_again()->row_idx[D.row_idx_off + r] : (uint64_t)r;
+        return mat[row * D.row_stride + site0 - (uint32_t)(-rel)];
       };
       cp.joint_columns(
           [&](int rel) {
@@ -257,21 +295,17 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
             for (uint32_t r = lane; r < N; r += 64u) Mv |= codon_bit(cell(r, rel), cell(r, rel + 1), cell(r, rel + 2));
             return Mv;
           },
-          hsite_get);
-      // carry the last two columns (bytes of every row) into the next tile
-      for (uint32_t i = lane; i < N; i += 64u) {
-        carry[2u * i] = tile8[i * TW + TW - 2u];
-        carry[2u * i + 1u] = tile8[i * TW + TW - 1u];
-      }
+          hget_uniform);
       // ---- nothing below reads the tile buffer: request the next tile now
       wave_lds_sync();
       if (tile + 1u < t1) stage(tile + 1u);
-      cp.mono_and_single_columns(hsite_get);
+      cp.mono_and_single_columns(hget_lane);
       if (tile + 1u == n_tiles) cp.last_tile(L);
       // H of the last two sites, for the codons that straddle into the next tile
-      if (lane < 2u) {
-        if (h16) hsite16[(int)lane - 2] = hsite16[TW - 2u + lane];
-        else hsite32[(int)lane - 2] = hsite32[TW - 2u + lane];
+      if (lane == 63u) {
+        const uint32_t i2 = (idx4 >> 16) & 0xFFu, i3 = idx4 >> 24;
+        if (wide_list) { list32[-2] = list32[i2]; list32[-1] = list32[i3]; }
+        else { list16[-2] = list16[i2]; list16[-1] = list16[i3]; }
       }
     } else {
       wave_lds_sync();   // every read of the tile buffer is done: request the next tile
@@ -284,14 +318,15 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   acc_bad = wave_sum(acc_bad);
   acc_H = wave_sum(acc_H);
   const kernarg_ptr_t K = kernargs_again();
+  const uint32_t rep_off = (blockIdx.y & K->rep_mask) * K->rep_stride;   // this chunk's output replica
   if (lane == 0u) {
-    pfa_result* const R = K->results + unit;
-    if (acc_S) atomicAdd(&R->seg_sites, acc_S);
-    if (acc_bad) atomicAdd(&R->sfs_bad, acc_bad);
+    pfa_result* const R = replica(K->results, rep_off) + unit;
+    // seg_sites and sfs_bad are neighbours in the record: one 64-bit add (neither can carry: < 2^32 sites)
+    if (acc_S | acc_bad) atomicAdd(reinterpret_cast<unsigned long long*>(&R->seg_sites), (unsigned long long)acc_S | (unsigned long long)acc_bad << 32);
     if (acc_H) atomicAdd(reinterpret_cast<unsigned long long*>(&R->H), acc_H);
   }
   wave_lds_sync();
-  uint32_t* const sfs = K->sfs + D.sfs_off;
+  uint32_t* const sfs = replica(K->sfs, rep_off) + D.sfs_off;
   for (uint32_t i = lane; i < nbins; i += 64u) {
     const uint32_t v = hist[i];
     if (v) atomicAdd(&sfs[i], v);

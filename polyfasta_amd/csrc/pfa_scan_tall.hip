@@ -118,8 +118,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   const uint32_t* const ridx = A.row_idx + (mapped ? D.row_idx_off : 0u);
   const bool multi = N > R;
   for (uint32_t i = lane; i < HB; i += 64u) hist[i] = 0u;
-  if (cds)
-    for (uint32_t i = lane; i < PFA_SYN_BINS; i += 64u) synhist[i] = 0u;
+  if (cds && lane < kSynLdsBins) synhist[lane] = 0u;
   // lane r holds the matrix row of the chunk's row r; the next chunk's are fetched while this one is scanned
   uint32_t idx_cur = 0u;
   const uint32_t stride16 = D.row_stride >> 4;
@@ -131,7 +130,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   const uint8_t* const mat = A.bases + D.base_off;
   const unsigned long long NN = (unsigned long long)N * N;
   CodonPass<BITMAPS> cp;
-  if constexpr (HAS_CDS) cp.init(lane, synhist, A, D);
+  if constexpr (HAS_CDS) cp.init(lane, unit, synhist, A, D);
   auto hsite_get = [&](int rel) -> HMask<HT> {
     const HT v = hsite[rel];
     return {v & (((HT)1 << MSH) - 1u), (uint32_t)(v >> MSH)};
@@ -147,7 +146,10 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     const uint32_t second = umax(umin(hi1, hi2), umax(lo1, lo2));
     if (second == 0u) acc_bad += 1u;
     else if (second - 1u < HB) atomicAdd(&hist[second - 1u], 1u);
-    else atomicAdd(&kernargs_again()->sfs[D.sfs_off + second - 1u], 1u);
+    else {
+      const kernarg_ptr_t K = kernargs_again();
+      atomicAdd(replica(K->sfs, (blockIdx.y & K->rep_mask) * K->rep_stride) + D.sfs_off + second - 1u, 1u);
+    }
   };
 
   // word offset of a codon in its row (read-back of columns that no codon slot tracked): the last
@@ -544,14 +546,14 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   acc_bad = wave_sum(acc_bad);
   acc_H = wave_sum(acc_H);
   const kernarg_ptr_t K = kernargs_again();
+  const uint32_t rep_off = (blockIdx.y & K->rep_mask) * K->rep_stride;   // this chunk's output replica
   if (lane == 0u) {
-    pfa_result* const Rz = K->results + unit;
-    if (acc_S) atomicAdd(&Rz->seg_sites, acc_S);
-    if (acc_bad) atomicAdd(&Rz->sfs_bad, acc_bad);
+    pfa_result* const Rz = replica(K->results, rep_off) + unit;
+    if (acc_S | acc_bad) atomicAdd(reinterpret_cast<unsigned long long*>(&Rz->seg_sites), (unsigned long long)acc_S | (unsigned long long)acc_bad << 32);
     if (acc_H) atomicAdd(reinterpret_cast<unsigned long long*>(&Rz->H), acc_H);
   }
   wave_lds_sync();
-  uint32_t* const sfs = K->sfs + D.sfs_off;
+  uint32_t* const sfs = replica(K->sfs, rep_off) + D.sfs_off;
   for (uint32_t i = lane; i < HB; i += 64u) {
     const uint32_t v = hist[i];
     if (v) atomicAdd(&sfs[i], v);

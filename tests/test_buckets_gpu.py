@@ -50,7 +50,8 @@ def test_mixed_batch_runs_every_unit_on_its_own_kernel(gpu):
     dev.upload(bases)
     plan = scan.Plan(table)
     assert plan.n_launches >= 5, plan.description
-    assert "scan_tall_kernel" in plan.description and "tw=128" in plan.description and "tw=256" in plan.description
+    assert "scan_tall_kernel<cds=1" in plan.description and "scan_tall_kernel<cds=0" in plan.description
+    assert "scan_kernel<cds=1" in plan.description and "scan_kernel<cds=0" in plan.description
     plan.run(dev)
     out = plan.fetch()
     for i, (mi, cds, rows) in enumerate(specs):
@@ -132,3 +133,31 @@ def test_sfs_flag_prints_the_folded_spectrum(gpu, tmp_path):
     with redirect_stdout(buf):
         assert cli.main(["-f", str(tmp_path / "gap.fa"), "--sfs", "-s"]) == 0
     assert buf.getvalue().rstrip("\n").split(",")[-1] == "NA"
+
+
+@pytest.mark.parametrize("replicas", [None, 1, 4, 32])
+def test_output_replicas_sum_to_the_oracle(gpu, monkeypatch, replicas):
+    """plans with few units and many chunks per unit spread their atomics over replicas of the output
+    slab; the fetch sums them (64-bit H fields as 64-bit integers, the rest as 32-bit counters)"""
+    if replicas is not None:
+        monkeypatch.setenv("PFA_REPLICAS", str(replicas))
+    p = synth.make_params(50, 0.01)
+    b = scan.Batch(stride_align=128)
+    mats = [synth.synth_alignment(3, 0, 10000, p), synth.synth_alignment(3, 1, 9000, p, coding=True)]
+    b.add_unit(b.add_matrix(mats[0]))
+    b.add_unit(b.add_matrix(mats[1]), cds=True)
+    b.add_unit(1, rows=np.arange(0, 50, 3, dtype=np.uint32), cds=True)
+    bases, table = b.pack()
+    dev = scan.DeviceBuffer(len(bases))
+    dev.upload(bases)
+    plan = scan.Plan(table)
+    if replicas is None:
+        assert "output replicas" in plan.description, plan.description
+    for _ in range(3):
+        plan.run(dev)
+        out = plan.fetch()
+        _check(out, 0, mats[0])
+        _check(out, 1, mats[1], cds=True)
+        _check(out, 2, mats[1], cds=True, rows=np.arange(0, 50, 3))
+    plan.close()
+    dev.free()

@@ -97,3 +97,31 @@ def test_cli_gpus_flag_refuses_a_mismatched_launcher(monkeypatch, capsys):
     monkeypatch.setenv("RANK", "0")
     assert cli.main(["-f", "x.fa", "--gpus", "4"]) == 2
     assert "--gpus 4" in capsys.readouterr().err
+
+
+def test_unique_id_rendezvous_under_torchrun(tmp_path):
+    """the launcher-derived rendezvous name under the real `torch.distributed.run` (how the driver starts
+    bench.py on N GPUs): both ranks end up with the bytes rank 0 made, and the file is a fresh one"""
+    script = tmp_path / "rdzv.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        from polyfasta_amd import dist
+        rank, local, world = dist.env_world()
+        assert "PFA_RDZV_FILE" not in os.environ
+        blob = dist.exchange_unique_id(rank, lambda: os.urandom(128), 128, timeout=60)
+        open(os.path.join({str(tmp_path)!r}, f"got{{rank}}"), "wb").write(blob)
+        open(os.path.join({str(tmp_path)!r}, f"path{{rank}}"), "w").write(dist.rendezvous_path())
+    """))
+    for attempt in range(2):          # a second job of the same shape must not pick up the first one's id
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+        env = {k: v for k, v in os.environ.items() if k != "PFA_RDZV_FILE"}
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-2000:]
+        a, b = open(tmp_path / "got0", "rb").read(), open(tmp_path / "got1", "rb").read()
+        assert a == b and len(a) == 128
+        assert open(tmp_path / "path0").read() == open(tmp_path / "path1").read()
+        if attempt:
+            assert a != first
+        first = a

@@ -162,16 +162,23 @@ def test_tall_kernel_forced_on_small_units(gpu, monkeypatch, rows_per_chunk, slo
         _compare(out, i, c_oracle.scan(m, rows=rows, want_sites=True), False)
 
 
-def test_too_many_rows_is_refused(gpu):
-    """coding units must fit one LDS column tile; non-coding units are streamed in row chunks"""
+def test_row_limit(gpu):
+    """no limit below the 32-bit counters' (the reference has none, PolyFastA.py:284-315): coding units
+    above 2 048 rows run the wide instantiation of the row-chunked kernel; PFA_MAX_ROWS is refused"""
     from polyfasta_amd import _lib
-    m = np.full((2049, 32), 65, dtype=np.uint8)
-    with pytest.raises(_lib.PfaError) as e:
-        scan.scan_matrix(m, cds=True)
-    assert e.value.code == -5
+    m = np.full((2049, 33), 65, dtype=np.uint8)
     m[7, 3] = 67
-    r = scan.scan_matrix(m).results[0]
-    assert (int(r["seg_sites"]), int(r["H"])) == (1, 2049 * 2049 - 2048 * 2048 - 1)
+    for cds in (False, True):
+        r = scan.scan_matrix(m, cds=cds).results[0]
+        assert (int(r["seg_sites"]), int(r["H"])) == (1, 2049 * 2049 - 2048 * 2048 - 1)
+    o = c_oracle.scan(m, cds=True)
+    assert (int(r["seg_S"]), int(r["seg_N"]), int(r["H_S"]), int(r["H_N"]), int(r["missing_cols"])) == \
+           (o["seg_S"], o["seg_N"], o["H_S"], o["H_N"], o["missing_cols"])
+    d = np.zeros(1, dtype=_lib.DESC_DTYPE)
+    d["n_rows"], d["n_sites"], d["row_stride"], d["mat_rows"], d["row_idx_off"] = _lib.PFA_MAX_ROWS + 1, 16, 16, _lib.PFA_MAX_ROWS + 1, _lib.PFA_NO_ROW_IDX
+    with pytest.raises(_lib.PfaError) as e:
+        scan.Plan(scan.finalize_layout(d, None, 16 * (_lib.PFA_MAX_ROWS + 1)))
+    assert e.value.code == -5
 
 
 @pytest.mark.parametrize("rows_per_chunk,slots,seed", [(8, 16, 0), (12, 64, 1), (36, 64, 2), (8, 256, 3), (64, 32, 4)])
@@ -222,7 +229,7 @@ def test_random_many_row_batches_lean_kernels(gpu, seed, cds):
         b.add_unit(b.add_matrix(m), cds=cds)
         units.append(m)
     plan = scan.Plan(b.pack()[1])
-    assert plan.rows_per_chunk > 0
+    assert "scan_tall_kernel<cds=%d,mapped=0,bitmaps=0" % int(cds) in plan.description, plan.description
     plan.close()
     out = scan.scan_batch(b)
     from polyfasta_amd import stats
