@@ -140,17 +140,14 @@ def small_launches(hw, args):
     rep = {}
     one = scan.Plan(scan.finalize_layout(hw.descs[:1].copy(), None, hw.nbytes))
     for _ in range(20):
-        one.run(hw.dev)
-        one.fetch()
+        one.run_fetch(hw.dev)
     t1 = time.perf_counter()
     for _ in range(500):
-        one.run(hw.dev)
-        one.fetch()
+        one.run_fetch(hw.dev)
     per = (time.perf_counter() - t1) / 500
     _lib.check(lib.pfa_plan_set_timing(one.handle, 1))     # HIP events around the launch: kernel time alone
     for _ in range(60):
-        one.run(hw.dev)
-        one.fetch()
+        one.run_fetch(hw.dev)
     k = one.kernel_ms(50)
     rep["single_alignment"] = {"us_per_scan_and_fetch": per * 1e6, "kernel_us": float(k.mean()) * 1e3, "kernel_us_min": float(k.min()) * 1e3,
                                "plan": one.description,
@@ -158,8 +155,7 @@ def small_launches(hw, args):
     one.close()
     c3 = Workload(rows=100, sites=100000, batch=1, pops=2, theta=args.theta, stride_align=args.stride_align)
     for _ in range(20):
-        c3.plan.run(c3.dev)
-        c3.plan.fetch()
+        c3.plan.run_fetch(c3.dev)
     k = c3.plan.kernel_ms(16)
     rep["config3_one_launch"] = {"kernel_us": float(k.mean()) * 1e3, "kernel_us_min": float(k.min()) * 1e3,
                                  "bytes": c3.alg_bytes, "achieved_GBps": c3.alg_bytes / (float(k.mean()) * 1e-3) / 1e9,

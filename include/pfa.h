@@ -162,6 +162,9 @@ int pfa_plan_kernel_ms(pfa_plan* plan, float* ms_out, int n);
  * are served from the host copy. */
 int pfa_plan_fetch(pfa_plan* plan, pfa_result* results, uint32_t* sfs, uint32_t* syn_num,
                    uint64_t* var_bitmap, uint64_t* syn_bitmap, uint64_t* non_bitmap);
+/* pfa_plan_run() + pfa_plan_fetch() in one call (one scan per call: the latency path) */
+int pfa_plan_run_fetch(pfa_plan* plan, const uint8_t* d_bases, int variant, pfa_result* results, uint32_t* sfs,
+                       uint32_t* syn_num, uint64_t* var_bitmap, uint64_t* syn_bitmap, uint64_t* non_bitmap);
 /* device pointer of the result records (n_desc x pfa_result) of the last run,
  * valid until that run is fetched (pfa_comm_all_gather_results() reads them) */
 int pfa_plan_results_dev(pfa_plan* plan, void** d_results, size_t* bytes);

@@ -98,6 +98,7 @@ _PROTOTYPES = {
     "pfa_plan_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "pfa_plan_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
     "pfa_plan_fetch": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pfa_plan_run_fetch": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pfa_plan_results_dev": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_size_t)]),
     "pfa_plan_n_tiles": (ctypes.c_uint32, [_vp]),
     "pfa_plan_tiles_per_chunk": (ctypes.c_uint32, [_vp]),

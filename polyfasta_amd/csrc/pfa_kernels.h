@@ -24,6 +24,15 @@
 #include "pfa_common.h"
 #include "pfa_layout.h"
 
+// unroll depths of the row loops of tier 1 (LDS words) and tier 2 (column bytes): how many LDS
+// reads a wavefront keeps in flight per round trip (timing experiments may override them)
+#ifndef PFA_UNROLL_T1
+#define PFA_UNROLL_T1 8
+#endif
+#ifndef PFA_UNROLL_T2
+#define PFA_UNROLL_T2 4
+#endif
+
 namespace pfa {
 static constexpr ct::Tables kHostTables = ct::make_tables();   // also the source of literal constants in device code
 }

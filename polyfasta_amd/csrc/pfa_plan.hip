@@ -332,11 +332,15 @@ namespace pfa {
 //   other units: 256-site tiles up to 64 rows, 128-site tiles while those fill the CU (about 250
 //     rows), else the row-chunked kernel; tiny plans take narrower tiles for more wavefronts
 struct BucketKey {
-  uint32_t tall, cds, mapped, wide, tw, waves;
+  uint32_t tall, cds, mapped, wide, tw, waves, wg;   // waves: occupancy class; wg: wavefronts per workgroup (0: one)
   bool operator<(const BucketKey& o) const {
-    return std::tie(tall, cds, mapped, wide, tw, waves) < std::tie(o.tall, o.cds, o.mapped, o.wide, o.tw, o.waves);
+    return std::tie(tall, cds, mapped, wide, tw, waves, wg) < std::tie(o.tall, o.cds, o.mapped, o.wide, o.tw, o.waves, o.wg);
   }
 };
+
+// scan_wg_kernel: W wavefronts share a 256-site tile when a unit has too many rows for one
+// wavefront per tile to work well, and few enough for three workgroups (W = 4: 12 waves) per CU
+static constexpr uint32_t kWgMinRows = 65u, kWg2MaxRows = 128u, kWg4MaxRows = 208u;
 
 static BucketKey bucket_of(const pfa_desc& d, bool bitmaps, uint32_t narrow_tw) {
   BucketKey k{};
@@ -349,6 +353,11 @@ static BucketKey bucket_of(const pfa_desc& d, bool bitmaps, uint32_t narrow_tw) 
     const uint32_t lds = lds_layout(256u, n, k.cds, rowmap).total;
     k.tall = n > 64u && !classic_fills_cu(lds, n, 256u);
     if (getenv("PFA_TALL_MIN")) k.tall = n > env_u32("PFA_TALL_MIN", 64u) || lds > kLdsPerCu;
+  } else if (!narrow_tw && !env_u32("PFA_FORCE_TW", 0u) && !getenv("PFA_TALL_MIN") && env_u32("PFA_WG", 1u) &&
+             n >= kWgMinRows && n <= kWg4MaxRows) {
+    k.wg = n <= kWg2MaxRows ? 2u : 4u;
+    k.waves = std::min(kLdsPerCu / std::max(wg_layout(k.wg, n, k.mapped).total, 1u), 32u);
+    return k;
   } else {
     const uint32_t tw256_max = env_u32("PFA_TW256_MAX_ROWS", 64u);
     const uint32_t forced = env_u32("PFA_FORCE_TW", 0u);
@@ -396,7 +405,10 @@ static void finish_bucket(Bucket& b, const BucketKey& k, bool bitmaps, const pfa
     b.sum_tiles += nt;
     b.bytes += (uint64_t)d.n_rows * d.n_sites;
   }
-  if (b.tall) {
+  b.cfg.waves = k.wg ? k.wg : 1u;
+  if (k.wg) {
+    b.cfg.lds_bytes = wg_layout(k.wg, b.n_max, b.cfg.mapped).total;
+  } else if (b.tall) {
     // equal chunks of at most kTallRows rows (a multiple of 4: one LDS-DMA instruction moves 4 rows)
     const uint32_t rcap = std::min(64u, std::max(8u, env_u32("PFA_TALL_ROWS", kTallRows)));
     const uint32_t nc = (b.n_max + rcap - 1u) / rcap;
@@ -411,7 +423,7 @@ static void finish_bucket(Bucket& b, const BucketKey& k, bool bitmaps, const pfa
   // alignments per wave once the batch is large (fewer atomics).  96 single-wave workgroups per
   // CU measured best for the bench workload (10 tiles per chunk: 6.48 TB/s; 20 tiles 6.36,
   // 4 tiles 6.36, 1 tile 5.43)
-  const uint64_t target_blocks = (uint64_t)std::max(ctx().n_cu, 1) * 96ull;
+  const uint64_t target_blocks = (uint64_t)std::max(ctx().n_cu, 1) * 96ull / b.cfg.waves;
   uint64_t tpc = std::max<uint64_t>(1, b.sum_tiles / target_blocks);
   if (getenv("PFA_TILES_PER_CHUNK")) tpc = std::max(1u, env_u32("PFA_TILES_PER_CHUNK", 10u));   // timing experiments
   tpc = std::min<uint64_t>(tpc, std::max<uint32_t>(b.max_tiles, 1));
@@ -431,7 +443,10 @@ static std::string describe(const pfa_plan* p) {
   char buf[256];
   for (const Bucket& b : p->buckets) {
     if (!s.empty()) s += " | ";
-    if (b.tall)
+    if (b.cfg.waves > 1u)
+      snprintf(buf, sizeof buf, "pfa::scan_wg_kernel<waves=%u,mapped=%d> units=%u n_max=%u lds=%u tiles_per_chunk=%u", b.cfg.waves,
+               (int)b.cfg.mapped, b.cfg.n_units, b.n_max, b.cfg.lds_bytes, b.tiles_per_chunk);
+    else if (b.tall)
       snprintf(buf, sizeof buf, "pfa::scan_tall_kernel<cds=%d,mapped=%d,bitmaps=%d,wide=%d> units=%u n_max=%u rows_per_chunk=%u lds=%u tiles_per_chunk=%u",
                (int)b.cfg.cds, (int)(b.cfg.mapped || b.cfg.bitmaps), (int)(b.cfg.mapped || b.cfg.bitmaps), (int)b.cfg.wide, b.cfg.n_units, b.n_max, b.rows_per_chunk,
                b.cfg.lds_bytes, b.tiles_per_chunk);
@@ -665,8 +680,8 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
     a.rep_stride = (uint32_t)p->slab_bytes;
     pfa::LaunchCfg c = b.cfg;
     // the default-cache-policy variant exists for the 256-site lean / general instantiations (A/B)
-    c.stage = (variant == 2 && c.tw == 256u && !c.wide) ? 0 : 2;
-    const int rc = b.tall ? pfa::launch_tall(c, a, st) : pfa::launch_classic(c, a, st);
+    c.stage = (variant == 2 && c.tw == 256u && !c.wide && c.waves == 1u) ? 0 : 2;
+    const int rc = c.waves > 1u ? pfa::launch_wg(c, a, st) : b.tall ? pfa::launch_tall(c, a, st) : pfa::launch_classic(c, a, st);
     if (rc != PFA_OK) return rc;
   }
   if (slot >= 0) {
@@ -736,6 +751,12 @@ int pfa_plan_fetch(pfa_plan* p, pfa_result* results, uint32_t* sfs, uint32_t* sy
   }
   if (copies) PFA_HIP(hipStreamSynchronize(st));
   return PFA_OK;
+}
+
+int pfa_plan_run_fetch(pfa_plan* p, const uint8_t* d_bases, int variant, pfa_result* results, uint32_t* sfs,
+                       uint32_t* syn_num, uint64_t* var_bitmap, uint64_t* syn_bitmap, uint64_t* non_bitmap) {
+  const int rc = pfa_plan_run(p, d_bases, variant);
+  return rc != PFA_OK ? rc : pfa_plan_fetch(p, results, sfs, syn_num, var_bitmap, syn_bitmap, non_bitmap);
 }
 
 int pfa_plan_results_dev(pfa_plan* p, void** d_results, size_t* bytes) {

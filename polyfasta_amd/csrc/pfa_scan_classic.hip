@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     uint32_t va = 0xFFFFFFFFu, vo = 0u;
     {
       const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile8);
-#pragma unroll 8
+#pragma unroll PFA_UNROLL_T1
       for (uint32_t r = 0; r < steps; ++r) {
         const uint32_t x = t32[r * 64u + lane];
         va &= x;
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
         const uint8_t* colp = tile8 + s;
         const uint32_t x = colp[0], y = x ^ ((ent >> 8) & 0xFFu);
         uint32_t c1 = 0, c2 = 0;
-#pragma unroll 4
+#pragma unroll PFA_UNROLL_T2
         for (uint32_t r = ph; r < N; r += LPS) {
           const uint32_t v = colp[r * TW];
           c1 += (v == x);

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       const uint32_t x0w = reinterpret_cast<const uint32_t*>(tile8)[lane];   // first row of the chunk
       {
         const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile8);
-#pragma unroll 8
+#pragma unroll PFA_UNROLL_T1
         for (uint32_t r = 0; r < Rc; ++r) {
           const uint32_t x = t32[r * 64u + lane];
           ca &= x;
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
         bool need6 = act && mode == 1u;
         if (act && mode == 0u) {   // the same in all 4 lanes of the quad
           uint32_t c1 = 0, c2 = 0;
-#pragma unroll 4
+#pragma unroll PFA_UNROLL_T2
           for (uint32_t r = ph; r < Rc; r += 4u) {
             const uint32_t v = colp[r * TW];
             c1 += (v == x);

@@ -214,6 +214,7 @@ class Plan:
                                                _lib.ptr(table.row_idx) if len(table.row_idx) else None,
                                                len(table.row_idx), table.n_bases_bytes, self.want, ctypes.byref(h)))
         self.handle = h
+        self._cache = None
         if timing:
             _lib.check(_lib.load().pfa_plan_set_timing(h, 1))
 
@@ -226,20 +227,39 @@ class Plan:
         cnt = _lib.check(_lib.load().pfa_plan_kernel_ms(self.handle, buf, n))
         return np.array(buf[:cnt], dtype=np.float64)
 
-    def fetch(self) -> ScanOutput:
-        lib = _lib.load()
+    def _sizes(self):
+        if self._cache is None:
+            lib = _lib.load()
+            self._cache = (int(lib.pfa_plan_n_tiles(self.handle)), max(int(lib.pfa_plan_sfs_words(self.handle)), 1))
+        return self._cache
+
+    def _outputs(self):
         t = self.table
-        nt = int(lib.pfa_plan_n_tiles(self.handle))
-        res = np.zeros(t.n_units, dtype=RESULT_DTYPE)
-        sfs = np.zeros(max(int(lib.pfa_plan_sfs_words(self.handle)), 1), dtype=np.uint32)
-        syn = np.zeros((t.n_units, PFA_SYN_BINS), dtype=np.uint32) if self.any_cds else None
+        nt, sfs_words = self._sizes()
+        res = np.empty(t.n_units, dtype=RESULT_DTYPE)
+        sfs = np.empty(sfs_words, dtype=np.uint32)
+        if sfs_words == 1:
+            sfs[0] = 0
+        syn = np.empty((t.n_units, PFA_SYN_BINS), dtype=np.uint32) if self.any_cds else None
         vb = np.zeros(max(nt * t.var_words, 1), dtype=np.uint64) if self.want & _lib.PFA_WANT_VAR_BITMAP else None
         sn = bool(self.want & _lib.PFA_WANT_SN_BITMAP) and self.any_cds
         sb = np.zeros(max(nt * t.var_words, 1), dtype=np.uint64) if sn else None
         nb = np.zeros(max(nt * t.var_words, 1), dtype=np.uint64) if sn else None
-        _lib.check(lib.pfa_plan_fetch(self.handle, _lib.ptr(res), _lib.ptr(sfs), _lib.ptr(syn), _lib.ptr(vb),
-                                      _lib.ptr(sb), _lib.ptr(nb)))
-        return ScanOutput(table=t, results=res, sfs_flat=sfs, syn_num=syn, var_bitmap=vb, syn_bitmap=sb, non_bitmap=nb)
+        return res, sfs, syn, vb, sb, nb
+
+    def fetch(self) -> ScanOutput:
+        res, sfs, syn, vb, sb, nb = self._outputs()
+        _lib.check(_lib.load().pfa_plan_fetch(self.handle, _lib.ptr(res), _lib.ptr(sfs), _lib.ptr(syn), _lib.ptr(vb),
+                                              _lib.ptr(sb), _lib.ptr(nb)))
+        return ScanOutput(table=self.table, results=res, sfs_flat=sfs, syn_num=syn, var_bitmap=vb, syn_bitmap=sb, non_bitmap=nb)
+
+    def run_fetch(self, d_bases, variant: int = 0) -> ScanOutput:
+        """run + fetch in one call into the library (one scan per call: the latency path)"""
+        p = d_bases.ptr if isinstance(d_bases, DeviceBuffer) else ctypes.c_void_p(int(d_bases))
+        res, sfs, syn, vb, sb, nb = self._outputs()
+        _lib.check(_lib.load().pfa_plan_run_fetch(self.handle, p, int(variant), _lib.ptr(res), _lib.ptr(sfs), _lib.ptr(syn),
+                                                  _lib.ptr(vb), _lib.ptr(sb), _lib.ptr(nb)))
+        return ScanOutput(table=self.table, results=res, sfs_flat=sfs, syn_num=syn, var_bitmap=vb, syn_bitmap=sb, non_bitmap=nb)
 
     def results_dev(self):
         p = ctypes.c_void_p()

@@ -21,17 +21,14 @@ def probe(w, label):
             os.environ.pop("PFA_FORCE_TW", None)
         plan = scan.Plan(w.table)
         for _ in range(30):
-            plan.run(w.dev)
-            plan.fetch()
+            plan.run_fetch(w.dev)
         t0 = time.perf_counter()
         for _ in range(300):
-            plan.run(w.dev)
-            plan.fetch()
+            plan.run_fetch(w.dev)
         wall = (time.perf_counter() - t0) / 300
         _lib.check(lib.pfa_plan_set_timing(plan.handle, 1))
         for _ in range(60):
-            plan.run(w.dev)
-            plan.fetch()
+            plan.run_fetch(w.dev)
         k = plan.kernel_ms(50)
         print(f"{label} tw={tw or 'auto':4s} kernel_us avg {k.mean() * 1e3:7.2f} min {k.min() * 1e3:7.2f}  run+fetch {wall * 1e6:7.2f} us  "
               f"{w.alg_bytes / (k.mean() * 1e-3) / 1e9:8.1f} GB/s  {plan.description}", flush=True)
