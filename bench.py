@@ -320,8 +320,12 @@ def main():
 
     from polyfasta_amd import _lib
     lib = _lib.load()
-    _lib.init()                                   # GPU LOCAL_RANK; fails loudly when it is not there
-    comm = dist.RcclComm() if (world > 1 or os.environ.get("PFA_FORCE_DIST")) else None   # PFA_FORCE_DIST: 1-rank RCCL rehearsal
+    try:
+        _lib.init()                               # GPU LOCAL_RANK; fails loudly when it is not there
+        comm = dist.RcclComm() if (world > 1 or os.environ.get("PFA_FORCE_DIST")) else None   # PFA_FORCE_DIST: 1-rank RCCL rehearsal
+    except (_lib.PfaError, TimeoutError) as e:
+        print(f"bench.py: rank {rank} of {world}: {e} (one process per GPU: --gpus must not exceed the visible GPUs)", file=sys.stderr)
+        sys.exit(2)
 
     hw = Workload(args.rows, args.sites, args.batch, theta=args.theta, coding=args.coding, pops=args.pops,
                   stride_align=args.stride_align, first_aln=rank * args.batch)

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.environ.get("PFA_LIB") or os.path.join(_HERE, "libpfa_hip.so")
-SOURCES = ["pfa_scan_classic.hip", "pfa_scan_tall.hip", "pfa_scan_wg.hip", "pfa_plan.hip", "pfa_synth.hip", "pfa_comm.cpp",
+SOURCES = ["pfa_scan_classic.hip", "pfa_scan_tall.hip", "pfa_plan.hip", "pfa_synth.hip", "pfa_comm.cpp",
            "pfa_fasta.cpp", "pfa_format.cpp"]
 HEADERS = ["pfa_codon.h", "pfa_common.h", "pfa_kernels.h", "pfa_launch.h", "pfa_layout.h",
            os.path.join("..", "..", "include", "pfa.h")]

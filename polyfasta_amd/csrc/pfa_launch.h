@@ -18,12 +18,10 @@ struct LaunchCfg {
   bool mapped = false;       // ... units with a row-index list
   bool bitmaps = false;      // the plan wants per-site bitmaps
   bool wide = false;         // tall coding units above 2 048 rows: 56-bit per-site H
-  uint32_t waves = 1;        // wavefronts per workgroup: 1, or 2 / 4 (scan_wg_kernel)
 };
 
 int launch_classic(const LaunchCfg& c, const ScanArgs& a, hipStream_t st);
 int launch_tall(const LaunchCfg& c, const ScanArgs& a, hipStream_t st);
-int launch_wg(const LaunchCfg& c, const ScanArgs& a, hipStream_t st);
 int launch_classify_masks(const unsigned long long* d_masks, uint32_t n, uint32_t* d_labels, hipStream_t st);
 
 }  // namespace pfa

@@ -57,22 +57,6 @@ PFA_HD inline LdsLayout lds_layout(uint32_t tw, uint32_t n_max, bool cds, bool m
   return o;
 }
 
-// scan_wg_kernel (W wavefronts share a 256-site tile of all N rows)
-struct WgLayout {
-  uint32_t tile, xch, list, hist, rowmap, total;
-};
-PFA_HD inline WgLayout wg_layout(uint32_t waves, uint32_t n_max, bool mapped) {
-  const uint32_t n = n_max ? n_max : 1u;
-  WgLayout o;
-  o.tile = 0;
-  o.xch = round16(n * 256u);            // per wave and lane: the AND and OR words of the wave's rows
-  o.list = o.xch + waves * 512u;        // the tile's variable sites, one byte each
-  o.hist = o.list + 256u;
-  o.rowmap = o.hist + round16((n / 2u) * 4u + 4u);
-  o.total = o.rowmap + (mapped ? round16(n * 4u) : 0u);
-  return o;
-}
-
 // One launch = one bucket of a plan: units that share a kernel instantiation and an LDS size.
 struct ScanArgs {
   const uint8_t* bases;

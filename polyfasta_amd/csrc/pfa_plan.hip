@@ -54,13 +54,17 @@ __global__ void __launch_bounds__(256) sum_replicas_kernel(unsigned long long* _
                                                            uint32_t replicas, size_t stride64, size_t n_rec_words) {
   for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n64; w += (size_t)gridDim.x * blockDim.x) {
     const bool wide = w < n_rec_words && (w % 7u) < 3u;
-    unsigned long long acc = src[w];
-    src[w] = 0ull;
-    for (uint32_t r = 1; r < replicas; ++r) {
-      const unsigned long long v = src[w + r * stride64];
-      src[w + r * stride64] = 0ull;
-      acc = wide ? acc + v
-                 : (unsigned long long)((uint32_t)acc + (uint32_t)v) | (unsigned long long)((uint32_t)(acc >> 32) + (uint32_t)(v >> 32)) << 32;
+    unsigned long long acc = 0ull;
+    for (uint32_t r0 = 0; r0 < replicas; r0 += 8u) {   // eight independent loads in flight, then their zeros
+      unsigned long long v[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; ++k) v[k] = r0 + k < replicas ? src[w + (r0 + k) * stride64] : 0ull;
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; ++k) {
+        if (r0 + k < replicas) src[w + (r0 + k) * stride64] = 0ull;
+        acc = wide ? acc + v[k]
+                   : (unsigned long long)((uint32_t)acc + (uint32_t)v[k]) | (unsigned long long)((uint32_t)(acc >> 32) + (uint32_t)(v[k] >> 32)) << 32;
+      }
     }
     dst[w] = acc;
   }
@@ -332,15 +336,11 @@ namespace pfa {
 //   other units: 256-site tiles up to 64 rows, 128-site tiles while those fill the CU (about 250
 //     rows), else the row-chunked kernel; tiny plans take narrower tiles for more wavefronts
 struct BucketKey {
-  uint32_t tall, cds, mapped, wide, tw, waves, wg;   // waves: occupancy class; wg: wavefronts per workgroup (0: one)
+  uint32_t tall, cds, mapped, wide, tw, waves;   // waves: occupancy class
   bool operator<(const BucketKey& o) const {
-    return std::tie(tall, cds, mapped, wide, tw, waves, wg) < std::tie(o.tall, o.cds, o.mapped, o.wide, o.tw, o.waves, o.wg);
+    return std::tie(tall, cds, mapped, wide, tw, waves) < std::tie(o.tall, o.cds, o.mapped, o.wide, o.tw, o.waves);
   }
 };
-
-// scan_wg_kernel: W wavefronts share a 256-site tile when a unit has too many rows for one
-// wavefront per tile to work well, and few enough for three workgroups (W = 4: 12 waves) per CU
-static constexpr uint32_t kWgMinRows = 65u, kWg2MaxRows = 128u, kWg4MaxRows = 208u;
 
 static BucketKey bucket_of(const pfa_desc& d, bool bitmaps, uint32_t narrow_tw) {
   BucketKey k{};
@@ -353,11 +353,6 @@ static BucketKey bucket_of(const pfa_desc& d, bool bitmaps, uint32_t narrow_tw) 
     const uint32_t lds = lds_layout(256u, n, k.cds, rowmap).total;
     k.tall = n > 64u && !classic_fills_cu(lds, n, 256u);
     if (getenv("PFA_TALL_MIN")) k.tall = n > env_u32("PFA_TALL_MIN", 64u) || lds > kLdsPerCu;
-  } else if (!narrow_tw && !env_u32("PFA_FORCE_TW", 0u) && !getenv("PFA_TALL_MIN") && env_u32("PFA_WG", 1u) &&
-             n >= kWgMinRows && n <= kWg4MaxRows) {
-    k.wg = n <= kWg2MaxRows ? 2u : 4u;
-    k.waves = std::min(kLdsPerCu / std::max(wg_layout(k.wg, n, k.mapped).total, 1u), 32u);
-    return k;
   } else {
     const uint32_t tw256_max = env_u32("PFA_TW256_MAX_ROWS", 64u);
     const uint32_t forced = env_u32("PFA_FORCE_TW", 0u);
@@ -405,10 +400,7 @@ static void finish_bucket(Bucket& b, const BucketKey& k, bool bitmaps, const pfa
     b.sum_tiles += nt;
     b.bytes += (uint64_t)d.n_rows * d.n_sites;
   }
-  b.cfg.waves = k.wg ? k.wg : 1u;
-  if (k.wg) {
-    b.cfg.lds_bytes = wg_layout(k.wg, b.n_max, b.cfg.mapped).total;
-  } else if (b.tall) {
+  if (b.tall) {
     // equal chunks of at most kTallRows rows (a multiple of 4: one LDS-DMA instruction moves 4 rows)
     const uint32_t rcap = std::min(64u, std::max(8u, env_u32("PFA_TALL_ROWS", kTallRows)));
     const uint32_t nc = (b.n_max + rcap - 1u) / rcap;
@@ -423,7 +415,7 @@ static void finish_bucket(Bucket& b, const BucketKey& k, bool bitmaps, const pfa
   // alignments per wave once the batch is large (fewer atomics).  96 single-wave workgroups per
   // CU measured best for the bench workload (10 tiles per chunk: 6.48 TB/s; 20 tiles 6.36,
   // 4 tiles 6.36, 1 tile 5.43)
-  const uint64_t target_blocks = (uint64_t)std::max(ctx().n_cu, 1) * 96ull / b.cfg.waves;
+  const uint64_t target_blocks = (uint64_t)std::max(ctx().n_cu, 1) * 96ull;
   uint64_t tpc = std::max<uint64_t>(1, b.sum_tiles / target_blocks);
   if (getenv("PFA_TILES_PER_CHUNK")) tpc = std::max(1u, env_u32("PFA_TILES_PER_CHUNK", 10u));   // timing experiments
   tpc = std::min<uint64_t>(tpc, std::max<uint32_t>(b.max_tiles, 1));
@@ -443,10 +435,7 @@ static std::string describe(const pfa_plan* p) {
   char buf[256];
   for (const Bucket& b : p->buckets) {
     if (!s.empty()) s += " | ";
-    if (b.cfg.waves > 1u)
-      snprintf(buf, sizeof buf, "pfa::scan_wg_kernel<waves=%u,mapped=%d> units=%u n_max=%u lds=%u tiles_per_chunk=%u", b.cfg.waves,
-               (int)b.cfg.mapped, b.cfg.n_units, b.n_max, b.cfg.lds_bytes, b.tiles_per_chunk);
-    else if (b.tall)
+    if (b.tall)
       snprintf(buf, sizeof buf, "pfa::scan_tall_kernel<cds=%d,mapped=%d,bitmaps=%d,wide=%d> units=%u n_max=%u rows_per_chunk=%u lds=%u tiles_per_chunk=%u",
                (int)b.cfg.cds, (int)(b.cfg.mapped || b.cfg.bitmaps), (int)(b.cfg.mapped || b.cfg.bitmaps), (int)b.cfg.wide, b.cfg.n_units, b.n_max, b.rows_per_chunk,
                b.cfg.lds_bytes, b.tiles_per_chunk);
@@ -680,8 +669,8 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
     a.rep_stride = (uint32_t)p->slab_bytes;
     pfa::LaunchCfg c = b.cfg;
     // the default-cache-policy variant exists for the 256-site lean / general instantiations (A/B)
-    c.stage = (variant == 2 && c.tw == 256u && !c.wide && c.waves == 1u) ? 0 : 2;
-    const int rc = c.waves > 1u ? pfa::launch_wg(c, a, st) : b.tall ? pfa::launch_tall(c, a, st) : pfa::launch_classic(c, a, st);
+    c.stage = (variant == 2 && c.tw == 256u && !c.wide) ? 0 : 2;
+    const int rc = b.tall ? pfa::launch_tall(c, a, st) : pfa::launch_classic(c, a, st);
     if (rc != PFA_OK) return rc;
   }
   if (slot >= 0) {

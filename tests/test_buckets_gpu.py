@@ -161,37 +161,3 @@ def test_output_replicas_sum_to_the_oracle(gpu, monkeypatch, replicas):
         _check(out, 2, mats[1], cds=True, rows=np.arange(0, 50, 3))
     plan.close()
     dev.free()
-
-
-def test_multi_wave_workgroups_equal_the_oracle(gpu):
-    """units of 65 .. 208 rows in a plan large enough to matter run scan_wg_kernel (2 or 4 wavefronts share
-    a 256-site tile): every row split, odd symbols, row subsets (--pops), lengths ending inside a tile"""
-    b = scan.Batch(stride_align=128)
-    mats, specs = [], []
-    for i, (n, L) in enumerate([(65, 40000), (100, 30001), (128, 25000), (129, 33000), (200, 40000), (208, 26000),
-                                (66, 27001), (131, 29000), (97, 500), (199, 255), (150, 257)]):
-        p = synth.make_params(n, 0.02)
-        m = synth.synth_alignment(55, i, L, p)
-        if i % 3 == 1:
-            m = synth.inject_symbols(m, 11, 0.0005, b"-NRYK")
-        mid = b.add_matrix(m)
-        mats.append(m)
-        b.add_unit(mid)
-        specs.append((i, None))
-        if i % 2 == 0:
-            rows = np.arange(n - 1, -1, -2, dtype=np.uint32)      # every other row, backwards
-            b.add_unit(mid, rows=rows)
-            specs.append((i, rows))
-    bases, table = b.pack()
-    dev = scan.DeviceBuffer(len(bases))
-    dev.upload(bases)
-    plan = scan.Plan(table)
-    d = plan.description
-    assert "scan_wg_kernel<waves=2,mapped=0>" in d and "scan_wg_kernel<waves=4,mapped=0>" in d and "scan_wg_kernel<waves=2,mapped=1>" in d, d
-    for _ in range(2):
-        plan.run(dev)
-        out = plan.fetch()
-        for k, (mi, rows) in enumerate(specs):
-            _check(out, k, mats[mi], rows=rows)
-    plan.close()
-    dev.free()

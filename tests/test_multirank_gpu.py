@@ -91,13 +91,13 @@ print("rccl-one-rank-ok")
 
 def test_gpus_flag_fails_loudly_without_enough_gpus(gpu, tmp_path):
     """`--gpus 4` on a box with fewer GPUs: non-zero exit, a message, no rows (never a silent 1-GPU run)"""
-    have = dist.visible_gpu_count()
-    if have is None or have >= 4:
-        pytest.skip("needs a box with a readable topology and fewer than 4 GPUs")
+    if gpu.load().pfa_device_count() >= 4:
+        pytest.skip("needs a box with fewer than 4 GPUs")
     d = _make_dir(tmp_path, n_files=3)
     p = subprocess.run([sys.executable, "-m", "polyfasta_amd", "-d", str(d), "--gpus", "4"], cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
-    assert p.returncode != 0 and "--gpus 4" in p.stderr and "g00.fa" not in p.stdout
+    # refused by the launcher (readable kfd topology) or by the ranks whose GPU is not there
+    assert p.returncode != 0 and ("--gpus 4" in p.stderr or "out of range" in p.stderr) and "g00.fa" not in p.stdout
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0", "--batch", "8"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and '"n_gpus"' not in p.stdout

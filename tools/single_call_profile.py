@@ -1,24 +1,20 @@
 #!/usr/bin/env python3
-"""Where does one single-alignment CLI call spend its time? (config 2 shape, in-process, warm)"""
-import cProfile, io, os, pstats, sys, tempfile, time
-from contextlib import redirect_stdout
+"""One alignment per call, 300 times (under rocprofv3 --kernel-trace --stats: the kernel durations of
+the latency path, without the HIP-event overhead).  usage: ... -- python3 tools/single_call_profile.py [config3]"""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from polyfasta_amd import _lib, cli, synth
+import bench  # noqa: E402
+from polyfasta_amd import _lib, scan  # noqa: E402
+
 _lib.init(0)
-p = synth.make_params(50, 0.01)
-m = synth.synth_alignment(802, 0, 10000, p)
-d = tempfile.mkdtemp(prefix="pfa_one_", dir="/dev/shm")
-path = os.path.join(d, "x.fa")
-open(path, "w").write(synth.to_fasta_text(synth.headers_for(50), m))
-def run():
-    with redirect_stdout(io.StringIO()):
-        cli.main(["-f", path, "-s"])
-for _ in range(5): run()
-t0 = time.perf_counter()
-for _ in range(50): run()
-print("per call: %.3f ms" % ((time.perf_counter() - t0) / 50 * 1e3))
-pr = cProfile.Profile(); pr.enable()
-for _ in range(50): run()
-pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(18); print(s.getvalue()[:3500])
+if len(sys.argv) > 1 and sys.argv[1] == "config3":
+    w = bench.Workload(100, 100000, 1, pops=2, timing=False)
+else:
+    w = bench.Workload(50, 10000, 1, timing=False)
+for _ in range(300):
+    w.plan.run_fetch(w.dev)
+print(w.plan.description)
+w.close()
