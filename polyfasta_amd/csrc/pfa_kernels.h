@@ -171,8 +171,9 @@ __device__ inline uint32_t classify_uniform(unsigned long long ms, uint32_t lane
 // ---------------------------------------------------------------- the coding pass
 // Everything the syn / nonsyn split does once the allele scan of a tile is complete
 // (PolyFastA.py:284-315, 319-434), shared by scan_kernel and scan_tall_kernel.  Tiles are 256
-// sites wide and line-aligned; 256 = 1 (mod 3), so the first codon of tile t starts
-// t mod 3 sites before it: the tier-1 words of the previous tile's last lane are carried in
+// sites wide and line-aligned (scan_kernel also runs it on 128-site tiles: the lanes of the second
+// row group then own no site); 256 = 1 (mod 3), so the first codon of tile t starts
+// t mod 3 sites before it (128 = 2 (mod 3): 2t mod 3): the tier-1 words of the previous tile's last lane are carried in
 // registers, and chunks of coding plans hold a multiple of 3 tiles, so a chunk always starts
 // on a codon boundary.  What a kernel supplies: the tile's tier-1 words, a reader of the per-site
 // HMask (variable sites only), and a reader of the codon set of one column.
@@ -181,7 +182,8 @@ template <bool BITMAPS>
 struct CodonPass {
   static constexpr uint32_t LB = 4u, WW = 64u * LB, NIT = 2u;
   // wave constants: lane c stands for codon c in the tables below
-  uint32_t lane;
+  uint32_t lane, lane3;           // lane, lane mod 3
+  uint32_t last_lane;             // lane that owns the tile's last four sites (63; 31 for 128-site tiles)
   uint32_t my_info;               // annot_info[c] (classify_uniform)
   unsigned long long my_same;     // same_annot[c]
   uint32_t my_cinfo;              // synonymous-neighbour count | stop << 7, read with ds_bpermute
@@ -204,8 +206,10 @@ struct CodonPass {
   uint32_t pv[2];                 // the variable position of a `single` column
   uint32_t site0;
 
-  __device__ void init(uint32_t lane_, uint32_t unit_, uint32_t* synhist_, const ScanArgs& A, const pfa_desc& D) {
+  __device__ void init(uint32_t lane_, uint32_t unit_, uint32_t* synhist_, const ScanArgs& A, const pfa_desc& D, uint32_t last_lane_ = 63u) {
     lane = lane_;
+    last_lane = last_lane_;
+    lane3 = lane_ % 3u;
     unit = unit_;
     rep_off = (blockIdx.y & A.rep_mask) * A.rep_stride;
     synhist = synhist_;
@@ -232,6 +236,14 @@ struct CodonPass {
     else atomicAdd(replica(kernargs_again()->syn_num, rep_off) + (uint64_t)unit * PFA_SYN_BINS + k, t3);
   }
 
+  // first of this lane's four sites that ends a codon: (5 - (site0 + 4 lane) mod 3) mod 3, without a
+  // division per tile: 4 = 1 (mod 3), so it is 2 - ((site0 mod 3 + lane mod 3) mod 3)
+  __device__ uint32_t first_codon_end(uint32_t site0_) const {
+    uint32_t m = site0_ % 3u + lane3;     // site0 is wave-uniform: scalar arithmetic
+    m -= m >= 3u ? 3u : 0u;
+    return 2u - m;
+  }
+
   __device__ void mark_site(bool is_s, int rel_site) const {
     const uint32_t site = site0 + (uint32_t)rel_site;   // rel_site may be -2..-1: previous tile
     const uint64_t w = (uint64_t)(tile_off + site / WW) * LB + (site % WW) % LB;
@@ -246,11 +258,11 @@ struct CodonPass {
     site0 = site0_;
     uint32_t pa = wave_shr1(va), pd = wave_shr1(vd);
     if (lane == 0u) { pa = carry_va; pd = carry_vd; }
-    carry_va = __builtin_amdgcn_readlane(va, 63);
-    carry_vd = __builtin_amdgcn_readlane(vd, 63);
+    carry_va = __builtin_amdgcn_readlane(va, last_lane);
+    carry_vd = __builtin_amdgcn_readlane(vd, last_lane);
     const unsigned long long Wa = (unsigned long long)pa | (unsigned long long)va << 32;
     const unsigned long long Wd = (unsigned long long)pd | (unsigned long long)vd << 32;
-    const uint32_t o1 = (5u - (site0 + 4u * lane) % 3u) % 3u;   // first own site that ends a codon
+    const uint32_t o1 = first_codon_end(site0);
 #pragma unroll
     for (uint32_t it = 0; it < 2u; ++it) {
       const uint32_t o = o1 + 3u * it;
@@ -356,16 +368,18 @@ struct CodonPass {
     // equals it), then one table read: synonymous weight | stop << 7.  Every lane computes and
     // looks up, so that the ds_bpermute runs with all lanes enabled (a disabled lane would not
     // supply its table entry).
+    uint32_t bad_[2], cidx_[2];   // per candidate column: unclean-byte flags (one byte each), codon index of the consensus bytes
 #pragma unroll
     for (uint32_t it = 0; it < NIT; ++it) {
       const uint32_t w = xw[it];
       const uint32_t t2 = w & 0x060606u;
       const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
-      const uint32_t bad = (0x414141u + t2 + (e2 << 4) - e2) ^ w;
-      const uint32_t tt = t2 >> 1;
-      const uint32_t ci = lane_lookup(((tt & 3u) << 4) | ((tt >> 6) & 0xCu) | ((tt >> 16) & 3u), my_cinfo);
+      bad_[it] = (0x414141u + t2 + __umul24(e2, 15u)) ^ w;
+      // 2-bit codes at bits 1, 9, 17 of t2 -> 16 c0 + 4 c1 + c2: one 24-bit multiply lines them up at bits 17..22
+      cidx_[it] = (__umul24(t2, 0x100401u) >> 17) & 0x3Fu;
+      const uint32_t ci = lane_lookup(cidx_[it], my_cinfo);
       if (mono[it]) {
-        if (bad == 0u) {
+        if (bad_[it] == 0u) {
           acc_syn1 += ci & 7u;
           acc_stops += ci >> 7;
         } else {
@@ -379,18 +393,15 @@ struct CodonPass {
     // labelled.  The two fixed bytes are the lane's consensus bytes; the allele mask and H of
     // the variable site come from the allele scan.  All lanes run it, `valid` marks the lanes
     // that own such a column (the table reads are ds_bpermute's and need every lane enabled).
-    auto single_col = [&](bool valid, uint32_t w, uint32_t p, int end_rel) {
+    auto single_col = [&](bool valid, uint32_t bad3, uint32_t cidx, uint32_t p, int end_rel) {
       const int rel = valid ? end_rel - 2 : 0;
       const auto hv = hget(rel + (int)p);
       const uint32_t am = valid ? hv.m : 0u;
-      // exactly-A/C/G/T test of the two fixed bytes (as above; the byte of position p is meaningless)
-      const uint32_t t2 = w & 0x060606u;
-      const uint32_t e2 = ((w >> 2) & 0x010101u) & ~(w >> 1);
-      const uint32_t bad = ((0x414141u + t2 + (e2 << 4) - e2) ^ w) & ~(0xFFu << (8u * p));
+      // exactly-A/C/G/T test of the two fixed bytes (the byte of position p is meaningless)
+      const uint32_t bad = bad3 & ~(0xFFu << (8u * p));
       const uint32_t k = bad ? 0u : (uint32_t)__popc(am);   // distinct clean codons
-      const uint32_t tt = t2 >> 1;
-      const uint32_t c0 = tt & 3u, c1 = (tt >> 8) & 3u, c2 = (tt >> 16) & 3u;
-      const uint32_t b4 = p == 0u ? (c1 << 2 | c2) : p == 1u ? (c0 << 2 | c2) : (c0 << 2 | c1);
+      // the two fixed bases out of the codon index 16 c0 + 4 c1 + c2
+      const uint32_t b4 = p == 0u ? (cidx & 15u) : p == 1u ? ((cidx >> 2) & 12u) | (cidx & 3u) : cidx >> 2;
       const uint32_t j = b4 * 16u + (am & 15u);             // entry of plane p
       const uint32_t w0 = lane_lookup(j >> 2, my_slut[0]), w1 = lane_lookup(j >> 2, my_slut[1]), w2 = lane_lookup(j >> 2, my_slut[2]);
       const uint32_t v = ((p == 0u ? w0 : p == 1u ? w1 : w2) >> (8u * (j & 3u))) & 0xFFu;
@@ -407,11 +418,11 @@ struct CodonPass {
     };
     const bool any1 = single[0] || single[1];
     if (__any(any1)) {
-      const uint32_t sel = single[0] ? 0u : 1u;
-      single_col(any1, sel ? xw[1] : xw[0], (sel ? pv[1] : pv[0]) % 3u, sel ? endo[1] : endo[0]);
+      const bool sel = !single[0];
+      single_col(any1, sel ? bad_[1] : bad_[0], sel ? cidx_[1] : cidx_[0], sel ? pv[1] : pv[0], sel ? endo[1] : endo[0]);
     }
     const bool both = single[0] && single[1];            // a lane owning two such columns: rare
-    if (__any(both)) single_col(both, xw[1], pv[1] % 3u, endo[1]);
+    if (__any(both)) single_col(both, bad_[1], cidx_[1], pv[1], endo[1]);
   }
 
   // the trailing 1-2 sites of an alignment whose length is not a multiple of 3 never form a

@@ -350,9 +350,17 @@ static BucketKey bucket_of(const pfa_desc& d, bool bitmaps, uint32_t narrow_tw) 
   k.tw = 256u;
   const bool rowmap = k.mapped || bitmaps;   // the instantiation with bitmaps also carries the row map
   if (k.cds || bitmaps) {
-    const uint32_t lds = lds_layout(256u, n, k.cds, rowmap).total;
-    k.tall = n > 64u && !classic_fills_cu(lds, n, 256u);
+    // coding units above 64 rows: 128-site tiles while those fill the CU (bitmaps are laid out per 256 sites)
+    const uint32_t forced = env_u32("PFA_FORCE_TW", 0u);
+    if (!bitmaps && (forced == 128u || (!forced && n > env_u32("PFA_TW256_MAX_ROWS", 64u)))) k.tw = 128u;
+    uint32_t lds = lds_layout(k.tw, n, k.cds, rowmap).total;
+    if (k.tw == 128u && n > 64u && !classic_fills_cu(lds, n, 128u) && !forced) {
+      k.tw = 256u;
+      lds = lds_layout(k.tw, n, k.cds, rowmap).total;
+    }
+    k.tall = n > 64u && !classic_fills_cu(lds, n, k.tw);
     if (getenv("PFA_TALL_MIN")) k.tall = n > env_u32("PFA_TALL_MIN", 64u) || lds > kLdsPerCu;
+    if (k.tall) k.tw = 256u;
   } else {
     const uint32_t tw256_max = env_u32("PFA_TW256_MAX_ROWS", 64u);
     const uint32_t forced = env_u32("PFA_FORCE_TW", 0u);

@@ -28,7 +28,7 @@ template <int STAGE, bool HAS_CDS, bool MAPPED, bool BITMAPS, int TWP>
 __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   using G = Geo<TWP>;
-  static_assert(!HAS_CDS || TWP == 256, "the coding pass works on 256-site tiles");
+  static_assert(!HAS_CDS || TWP >= 128, "the coding pass works on 256- and 128-site tiles");
   static_assert(!BITMAPS || TWP == 256, "bitmaps are laid out per 256-site tile");
   constexpr uint32_t TW = G::TW;
 
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   uint32_t acc_S = 0u, acc_bad = 0u;
   unsigned long long acc_H = 0ull;
   CodonPass<BITMAPS> cp;
-  if constexpr (HAS_CDS) cp.init(lane, unit, synhist, A, D);
+  if constexpr (HAS_CDS) cp.init(lane, unit, synhist, A, D, G::LPG - 1u);
 
   const uint8_t* const mat = A.bases + D.base_off;
   const uint32_t NN = N * N;
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       cp.mono_and_single_columns(hget_lane);
       if (tile + 1u == n_tiles) cp.last_tile(L);
       // H of the last two sites, for the codons that straddle into the next tile
-      if (lane == 63u) {
+      if (lane == G::LPG - 1u) {
         const uint32_t i2 = (idx4 >> 16) & 0xFFu, i3 = idx4 >> 24;
         if (wide_list) { list32[-2] = list32[i2]; list32[-1] = list32[i3]; }
         else { list16[-2] = list16[i2]; list16[-1] = list16[i3]; }
@@ -374,12 +374,12 @@ static int launch_features(const LaunchCfg& c, const ScanArgs& a, hipStream_t st
 }
 
 int launch_classic(const LaunchCfg& c, const ScanArgs& a, hipStream_t st) {
-  if (c.tw != 256u && (c.cds || c.bitmaps || c.stage != 2)) {
-    set_error("internal: narrow tiles serve non-coding launches without bitmaps only");
+  if (c.tw != 256u && (c.bitmaps || c.stage != 2 || (c.cds && c.tw != 128u))) {
+    set_error("internal: narrow tiles serve launches without bitmaps only (coding: 128 sites)");
     return PFA_ERR_ARG;
   }
   if (c.stage == 0) return c.cds ? launch_features<0, true, 256>(c, a, st) : launch_features<0, false, 256>(c, a, st);
-  if (c.cds) return launch_features<2, true, 256>(c, a, st);
+  if (c.cds) return c.tw == 256u ? launch_features<2, true, 256>(c, a, st) : launch_features<2, true, 128>(c, a, st);
   if (c.tw == 256u) return launch_features<2, false, 256>(c, a, st);
   if (c.tw == 128u) return launch_features<2, false, 128>(c, a, st);
   return launch_features<2, false, 64>(c, a, st);

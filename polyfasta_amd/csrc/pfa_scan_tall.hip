@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     uint64_t jb_prev[2] = {0ull, 0ull};      // columns that were joint after the previous chunk
     uint64_t tracked[2] = {0ull, 0ull};      // joint columns of the finished tile whose set sits in a slot
     if (cds) {
-      const uint32_t o1 = (5u - (site0 + 4u * lane) % 3u) % 3u;
+      const uint32_t o1 = cp.first_codon_end(site0);
 #pragma unroll
       for (uint32_t it = 0; it < 2u; ++it) {
         const uint32_t o = o1 + 3u * it;

@@ -161,3 +161,57 @@ def test_output_replicas_sum_to_the_oracle(gpu, monkeypatch, replicas):
         _check(out, 2, mats[1], cds=True, rows=np.arange(0, 50, 3))
     plan.close()
     dev.free()
+
+
+def test_mixed_batch_costs_the_sum_of_its_parts(gpu):
+    """4 000 x (50 x 10 kb) plus 16 x (1 000 x 10 kb) in ONE plan: the 50-row units keep their kernel and
+    occupancy (round 1 moved the whole plan onto the row-chunked kernel), so the mixed plan takes about
+    what the two homogeneous plans take together; its rows equal the oracle's"""
+    import ctypes
+    import json
+    lib = _lib.load()
+    L = 10000
+    stride = scan.row_stride_for(L, 128)
+    parts = []
+    off = 0
+    for n_aln, n in ((4000, 50), (16, 1000)):
+        p = synth.make_params(n, 0.01)
+        parts.append((n_aln, n, p, off))
+        off += n_aln * n * stride
+    dev = scan.DeviceBuffer(off)
+    descs = []
+    for n_aln, n, p, o in parts:
+        sp = _lib.SynthParamsC(seed=99, first_aln=0, n_aln=n_aln, n_rows=n, n_sites=L, row_stride=stride,
+                               seg_thresh=p.seg_thresh, tri_thresh=p.tri_thresh, n_units=len(p.units), coding=0)
+        _lib.check(lib.pfa_synth_fill_dev(ctypes.c_void_p(dev.ptr.value + o), ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(p.cdf)),
+                                          _lib.ptr(np.ascontiguousarray(p.units))))
+        d = np.zeros(n_aln, dtype=_lib.DESC_DTYPE)
+        d["base_off"] = o + np.arange(n_aln, dtype=np.uint64) * np.uint64(n * stride)
+        d["n_rows"], d["n_sites"], d["row_stride"], d["mat_rows"], d["row_idx_off"] = n, L, stride, n, _lib.PFA_NO_ROW_IDX
+        descs.append(d)
+
+    def timed(d):
+        plan = scan.Plan(scan.finalize_layout(d.copy(), None, off), timing=True)
+        for _ in range(12):
+            plan.run(dev)
+        _lib.check(lib.pfa_sync())
+        ms = float(np.sort(plan.kernel_ms(10))[:5].mean())
+        out = plan.fetch()
+        desc = plan.description
+        plan.close()
+        return ms, out, desc
+
+    ms_small, out_small, _ = timed(descs[0])
+    ms_big, out_big, _ = timed(descs[1])
+    ms_mixed, out_mixed, desc = timed(np.concatenate(descs))
+    assert "scan_tall_kernel" in desc and "scan_kernel<cds=0,mapped=0,bitmaps=0,tw=256>" in desc, desc
+    assert (out_mixed.results[:4000] == out_small.results).all() and (out_mixed.results[4000:] == out_big.results).all()
+    for k, (n_aln, n, p, o) in enumerate(parts):           # one unit of each kind against the oracle
+        m = synth.synth_alignment(99, 3, L, p)
+        oc = c_oracle.scan(m)
+        r = (out_small, out_big)[k].results[3]
+        assert (int(r["seg_sites"]), int(r["H"])) == (oc["S"], oc["H"])
+    report = {"ms_4000x50": ms_small, "ms_16x1000": ms_big, "ms_mixed": ms_mixed, "ratio": ms_mixed / (ms_small + ms_big), "plan": desc}
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(report, open("gpurun_out/mixed_batch.json", "w"), indent=1)
+    assert ms_mixed <= 1.10 * (ms_small + ms_big), report
