@@ -145,11 +145,18 @@ def small_launches(hw, args):
     for _ in range(500):
         one.run_fetch(hw.dev)
     per = (time.perf_counter() - t1) / 500
+    # the same through the C ABI alone: caller-owned output arrays made once, one pfa_plan_run_fetch() per scan
+    res, sfs = np.empty(1, dtype=_lib.RESULT_DTYPE), np.empty(max(hw.N // 2, 1), dtype=np.uint32)
+    a_plan, a_dev, a_res, a_sfs = one.handle, hw.dev.ptr, _lib.ptr(res), _lib.ptr(sfs)
+    t1 = time.perf_counter()
+    for _ in range(500):
+        lib.pfa_plan_run_fetch(a_plan, a_dev, 0, a_res, a_sfs, None, None, None, None)
+    per_abi = (time.perf_counter() - t1) / 500
     _lib.check(lib.pfa_plan_set_timing(one.handle, 1))     # HIP events around the launch: kernel time alone
     for _ in range(60):
         one.run_fetch(hw.dev)
     k = one.kernel_ms(50)
-    rep["single_alignment"] = {"us_per_scan_and_fetch": per * 1e6, "kernel_us": float(k.mean()) * 1e3, "kernel_us_min": float(k.min()) * 1e3,
+    rep["single_alignment"] = {"us_per_scan_and_fetch": per * 1e6, "us_per_scan_and_fetch_c_abi": per_abi * 1e6, "kernel_us": float(k.mean()) * 1e3, "kernel_us_min": float(k.min()) * 1e3,
                                "plan": one.description,
                                "note": "one N x L alignment per launch, bases resident, records fetched after every scan"}
     one.close()

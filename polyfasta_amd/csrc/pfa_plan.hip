@@ -334,7 +334,7 @@ namespace pfa {
 //   coding units, and every unit of a plan that wants bitmaps: 256-site tiles; LDS-resident rows
 //     while they fill the CU, else the row-chunked kernel (wide above 2 048 coding rows)
 //   other units: 256-site tiles up to 64 rows, 128-site tiles while those fill the CU (about 250
-//     rows), else the row-chunked kernel; tiny plans take narrower tiles for more wavefronts
+//     rows), else the row-chunked kernel; tiny plans take 128-site tiles whatever their rows: more wavefronts
 struct BucketKey {
   uint32_t tall, cds, mapped, wide, tw, waves;   // waves: occupancy class
   bool operator<(const BucketKey& o) const {
@@ -545,7 +545,9 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
     // (more, smaller wavefront jobs: latency, not bandwidth, decides there).
     const bool bitmaps = want != 0u;
     const uint64_t n_cu = (uint64_t)std::max(pfa::ctx().n_cu, 1);
-    const uint32_t narrow_tw = tiles256_live < n_cu * 2ull ? 64u : tiles256_live < n_cu * 4ull ? 128u : 0u;
+    // (64-site tiles never beat 128-site ones — one alignment per launch 7.6 against 7.7 us, config 3 as one
+    // launch 13.7 against 10.8 — so they stay a PFA_FORCE_TW measurement variant)
+    const uint32_t narrow_tw = tiles256_live < n_cu * 4ull ? 128u : 0u;
     std::map<pfa::BucketKey, pfa::Bucket> bmap;
     for (uint32_t i = 0; i < n_desc; ++i) {
       if (pfa::tiles_of(descs[i], PFA_TILE_SITES) == 0u) continue;   // empty units: their records stay zero
