@@ -12,7 +12,7 @@
 //   tier 2  4 lanes per variable site walk the column out of LDS: two-allele fast path
 //           (x = row 0's byte, y = x ^ XOR byte), else six counters A C G T - N, else an exact
 //           generic path (sum_i #{j : x_j = x_i}); H, SFS bin (LDS histogram), optional bitmaps
-//   coding  register window over the tier-1 words (CodonPass, pfa_kernels.h); 256-site tiles only
+//   coding  register window over the tier-1 words (CodonPass, pfa_kernels.h); 256- and 128-site tiles
 // Reference: getvarsites PolyFastA.py:252-261, nucleotide_diversity :485-492, getsfs :274-282,
 // getvarCDSsites :284-315, get_syn_nonsyn_cod_sites :319-434.
 #include "pfa_kernels.h"
