@@ -577,7 +577,7 @@ def main(argv=None, comm=None):
         return 2
     try:                                   # the scan runs on the GPU or not at all: say so before any output
         _lib.init()                        # GPU LOCAL_RANK
-        if comm is None and world > 1:
+        if comm is None and (world > 1 or os.environ.get("PFA_FORCE_DIST")):   # PFA_FORCE_DIST: one-rank RCCL rehearsal
             comm = dist.RcclComm()
     except (_lib.PfaError, _lib.PfaLibraryError, TimeoutError) as e:
         print(f"polyfasta_amd: {e}", file=sys.stderr)

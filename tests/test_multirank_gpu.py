@@ -101,3 +101,15 @@ def test_gpus_flag_fails_loudly_without_enough_gpus(gpu, tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0", "--batch", "8"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and '"n_gpus"' not in p.stdout
+
+
+def test_cli_through_rccl_with_one_rank(gpu, tmp_path):
+    """the CLI's gather (records, synonymous bins, pickled metadata) through the real RCCL communicator,
+    one rank (PFA_FORCE_DIST): the CSV of the plain process, byte for byte"""
+    d = _make_dir(tmp_path, n_files=12)
+    argv = ["-d", str(d), "-s", "--cds", "--jc", "-p", "pop1,pop2", "--sfs"]
+    want = _single(argv)
+    env = dict(os.environ, PFA_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", PFA_RDZV_FILE=str(tmp_path / "id"))
+    p = subprocess.run([sys.executable, "-m", "polyfasta_amd"] + argv, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.stdout == want
