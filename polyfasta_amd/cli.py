@@ -238,10 +238,11 @@ def _attach(pending, out, done, want_sfs=False):
             done.append(ev)
 
 
-def process_files(indexed_paths, args):
+def process_files(indexed_paths, args, more=None):
     """Ingest (native multi-threaded packer), scan (one launch per batch) and
     return the ordered output events of the given (index, path) pairs
-    (PolyFastA.py:104-140)."""
+    (PolyFastA.py:104-140).  `more()` (multi-GPU work queue) hands out further pairs
+    whenever the local list runs dry, [] when there are none left."""
     done = []
     if args.pipe:
         for fidx, path in indexed_paths:
@@ -266,10 +267,16 @@ def process_files(indexed_paths, args):
     queue = deque(indexed_paths)
     want_names = bool(args.pops)
 
+    def refill():
+        if more is not None and not queue:
+            queue.extend(more())
+        return bool(queue)
+
     def next_chunk(cap):
         """files whose text adds up to at most ~85 % of a buffer (packed size ~ text size)"""
         chunk, size = [], 0
-        while queue and len(chunk) < FILES_PER_CALL:
+        # (shared work queue: one claim per batch — a rank never hoards what another could scan meanwhile)
+        while (queue or (not chunk and refill())) and len(chunk) < FILES_PER_CALL:
             try:
                 sz = os.path.getsize(queue[0][1])
             except OSError:
@@ -590,13 +597,18 @@ def main(argv=None, comm=None):
     if args.pipe:
         mine = [(0, paths[0])] if rank == 0 and paths else []
     elif world > 1:
-        mine = [(i, paths[i]) for i in dist.shard_by_size(_file_sizes(paths), world)[rank]]
+        mine = []          # everything comes out of the work queue the ranks share
     else:
         mine = list(enumerate(paths))
-    events = process_files(mine, args)
+    wq = None
+    if world > 1 and not args.pipe:
+        wq = dist.WorkQueue(_file_sizes(paths), world)
+    events = process_files(mine, args, more=(lambda: [(i, paths[i]) for i in wq.claim()]) if wq else None)
     if comm is not None:
         events = gather_events(comm, events)
         comm.barrier()
+    if wq is not None:
+        wq.close(unlink=rank == 0)       # every rank is past its last claim: the barrier above
     if rank == 0:
         emit(events, sink, args.cds, args.jc, args.sfs)
         if len(args.out) != 0 and not args.silent:                                 # :141-142

@@ -1,8 +1,9 @@
 """One process per GPU: sharding of independent alignments, the launcher and the final gather.
 
 The `--dir` batch mode of the reference is an embarrassingly parallel loop over files
-(PolyFastA.py:104).  Here the sorted file list is split over the ranks by size (largest
-first, always to the least loaded rank); no collective touches the data path.  When every
+(PolyFastA.py:104).  Here the ranks of a node drain one work queue of the sorted file list,
+largest files first (`WorkQueue`; `shard_by_size` is the static split for callers without a
+shared file system view); no collective touches the data path.  When every
 rank has scanned its share, the fixed-size integer result records travel through ONE RCCL
 all-gather (`pfa_comm_*` of the C ABI, include/pfa.h: librccl over xGMI, bound by the library
 itself — no torch anywhere); rank 0 finishes the floats and prints the rows in the
@@ -66,6 +67,46 @@ def shard_by_size(sizes, world: int):
 def shard_indices(n_items: int, rank: int, world: int, sizes=None):
     """Indices of the items rank `rank` owns (equal sizes when none are given)."""
     return shard_by_size(sizes if sizes is not None else [1] * n_items, world)[rank]
+
+
+class WorkQueue:
+    """The `--dir` loop as a work queue shared by the ranks of one node (north_star: "an
+    embarrassingly-parallel work queue"): the items, largest first, are claimed a few at a time
+    through a counter in a file next to the rendezvous file (`flock`); a rank that finishes early
+    simply claims more, so neither skewed file sizes nor a slow GPU decide the job time.  Which rank
+    scanned a file does not matter to the output: rank 0 orders the rows by file index."""
+
+    def __init__(self, sizes, world: int, path=None):
+        self.order = sorted(range(len(sizes)), key=lambda i: (-int(sizes[i]), i))
+        self.world = max(int(world), 1)
+        # a claim = 1/(4 world) of the items at most: even a small directory is spread over the ranks
+        self.grain = max(1, min(512, len(self.order) // (4 * self.world)))
+        self.path = path or rendezvous_path() + ".queue"
+        self.fd = os.open(self.path, os.O_RDWR | os.O_CREAT, 0o600)     # empty file = nothing claimed yet
+
+    def claim(self):
+        """the next item indices of this rank ([] when the queue is drained)"""
+        import fcntl
+        fcntl.flock(self.fd, fcntl.LOCK_EX)
+        try:
+            os.lseek(self.fd, 0, os.SEEK_SET)
+            raw = os.read(self.fd, 32)
+            lo = int(raw) if raw.strip() else 0
+            hi = min(lo + self.grain, len(self.order))
+            if hi > lo:
+                os.lseek(self.fd, 0, os.SEEK_SET)
+                os.write(self.fd, b"%-31d" % hi)
+        finally:
+            fcntl.flock(self.fd, fcntl.LOCK_UN)
+        return self.order[lo:hi]
+
+    def close(self, unlink=False):
+        if self.fd is not None:
+            os.close(self.fd)
+            self.fd = None
+        if unlink:
+            with contextlib.suppress(OSError):
+                os.unlink(self.path)
 
 
 # ---------------------------------------------------------------- launcher

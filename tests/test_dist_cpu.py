@@ -125,3 +125,33 @@ def test_unique_id_rendezvous_under_torchrun(tmp_path):
         if attempt:
             assert a != first
         first = a
+
+
+def test_work_queue_hands_out_every_item_once(tmp_path):
+    """the shared --dir work queue: four processes claim concurrently; every item exactly once, largest first"""
+    script = tmp_path / "claim.py"
+    script.write_text(textwrap.dedent(f"""
+        import json, sys, time
+        sys.path.insert(0, {ROOT!r})
+        from polyfasta_amd import dist
+        sizes = [1000 + (i * 7919) % 997 for i in range(1003)]
+        q = dist.WorkQueue(sizes, 4, {str(tmp_path / "q")!r})
+        got = []
+        while True:
+            c = q.claim()
+            if not c:
+                break
+            got.append(c)
+            time.sleep(0.05)      # a claim is followed by work: the other ranks get their turn
+        q.close()
+        json.dump(got, open({str(tmp_path)!r} + "/got" + sys.argv[1], "w"))
+    """))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)]) for r in range(4)]
+    assert all(p.wait(timeout=300) == 0 for p in procs)
+    claims = [c for r in range(4) for c in json.load(open(tmp_path / f"got{r}"))]
+    items = [i for c in claims for i in c]
+    assert sorted(items) == list(range(1003))
+    sizes = [1000 + (i * 7919) % 997 for i in range(1003)]
+    assert all(len(json.load(open(tmp_path / f"got{r}"))) > 0 for r in range(4))       # nobody starved
+    first = min(claims, key=lambda c: -sizes[c[0]])
+    assert sizes[first[0]] == max(sizes)                                                # the largest files go first
