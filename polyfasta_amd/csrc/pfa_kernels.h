@@ -178,11 +178,15 @@ __device__ inline uint32_t classify_uniform(unsigned long long ms, uint32_t lane
 // on a codon boundary.  What a kernel supplies: the tile's tier-1 words, a reader of the per-site
 // HMask (variable sites only), and a reader of the codon set of one column.
 // BITMAPS: the plan may want the per-site S / N bitmaps (compiled out otherwise).
-template <bool BITMAPS>
+// SPLIT (128-site tiles): both lane groups hold the tile's tier-1 words after the merge, so the two
+// candidate columns of a group-0 lane are shared out — lane j takes the first, its twin j + 32 the
+// second — and every per-column loop below runs once instead of twice.
+template <bool BITMAPS, bool SPLIT = false>
 struct CodonPass {
-  static constexpr uint32_t LB = 4u, WW = 64u * LB, NIT = 2u;
+  static constexpr uint32_t LB = 4u, WW = 64u * LB, NIT = SPLIT ? 1u : 2u;
   // wave constants: lane c stands for codon c in the tables below
-  uint32_t lane, lane3;           // lane, lane mod 3
+  uint32_t lane, lane3;           // lane, (lane within its group) mod 3
+  uint32_t jlane, it0;            // SPLIT: lane within its group of 32, which of the two candidate columns; else lane, 0
   uint32_t last_lane;             // lane that owns the tile's last four sites (63; 31 for 128-site tiles)
   uint32_t my_info;               // annot_info[c] (classify_uniform)
   unsigned long long my_same;     // same_annot[c]
@@ -209,7 +213,9 @@ struct CodonPass {
   __device__ void init(uint32_t lane_, uint32_t unit_, uint32_t* synhist_, const ScanArgs& A, const pfa_desc& D, uint32_t last_lane_ = 63u) {
     lane = lane_;
     last_lane = last_lane_;
-    lane3 = lane_ % 3u;
+    jlane = SPLIT ? lane_ & 31u : lane_;
+    it0 = SPLIT ? lane_ >> 5 : 0u;
+    lane3 = jlane % 3u;
     unit = unit_;
     rep_off = (blockIdx.y & A.rep_mask) * A.rep_stride;
     synhist = synhist_;
@@ -257,23 +263,23 @@ struct CodonPass {
   __device__ void window(uint32_t va, uint32_t vd, uint32_t site0_, uint32_t lim) {
     site0 = site0_;
     uint32_t pa = wave_shr1(va), pd = wave_shr1(vd);
-    if (lane == 0u) { pa = carry_va; pd = carry_vd; }
+    if (jlane == 0u) { pa = carry_va; pd = carry_vd; }
     carry_va = __builtin_amdgcn_readlane(va, last_lane);
     carry_vd = __builtin_amdgcn_readlane(vd, last_lane);
     const unsigned long long Wa = (unsigned long long)pa | (unsigned long long)va << 32;
     const unsigned long long Wd = (unsigned long long)pd | (unsigned long long)vd << 32;
     const uint32_t o1 = first_codon_end(site0);
 #pragma unroll
-    for (uint32_t it = 0; it < 2u; ++it) {
-      const uint32_t o = o1 + 3u * it;
-      const bool has = o < 4u && 4u * lane + o < lim;
+    for (uint32_t it = 0; it < NIT; ++it) {
+      const uint32_t o = o1 + 3u * (it0 + it);
+      const bool has = o < 4u && 4u * jlane + o < lim;
       xw[it] = (uint32_t)(Wa >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
       dw[it] = (uint32_t)(Wd >> (8u * (2u + (o & 3u)))) & 0xFFFFFFu;
-      endo[it] = has ? (int)(4u * lane + o) : -1;
+      endo[it] = has ? (int)(4u * jlane + o) : -1;
+      mjoint[it] = 0ull;
+      single[it] = mono[it] = false;
+      pv[it] = 0u;
     }
-    mjoint[0] = mjoint[1] = 0ull;
-    single[0] = single[1] = mono[0] = mono[1] = false;
-    pv[0] = pv[1] = 0u;
 #pragma unroll
     for (uint32_t it = 0; it < NIT; ++it) {
       bool joint = false;
@@ -368,7 +374,7 @@ struct CodonPass {
     // equals it), then one table read: synonymous weight | stop << 7.  Every lane computes and
     // looks up, so that the ds_bpermute runs with all lanes enabled (a disabled lane would not
     // supply its table entry).
-    uint32_t bad_[2], cidx_[2];   // per candidate column: unclean-byte flags (one byte each), codon index of the consensus bytes
+    uint32_t bad_[NIT], cidx_[NIT];   // per candidate column: unclean-byte flags (one byte each), codon index of the consensus bytes
 #pragma unroll
     for (uint32_t it = 0; it < NIT; ++it) {
       const uint32_t w = xw[it];
@@ -416,13 +422,17 @@ struct CodonPass {
       if (is_n) { acc_segN += 1u; acc_HN += hs; }
       if (BITMAPS && (is_s || is_n) && syn_bm != nullptr) mark_site(is_s, rel + (int)p);
     };
-    const bool any1 = single[0] || single[1];
-    if (__any(any1)) {
-      const bool sel = !single[0];
-      single_col(any1, sel ? bad_[1] : bad_[0], sel ? cidx_[1] : cidx_[0], sel ? pv[1] : pv[0], sel ? endo[1] : endo[0]);
+    if constexpr (SPLIT) {
+      if (__any(single[0])) single_col(single[0], bad_[0], cidx_[0], pv[0], endo[0]);
+    } else {
+      const bool any1 = single[0] || single[NIT - 1u];
+      if (__any(any1)) {
+        const bool sel = !single[0];
+        single_col(any1, sel ? bad_[NIT - 1u] : bad_[0], sel ? cidx_[NIT - 1u] : cidx_[0], sel ? pv[NIT - 1u] : pv[0], sel ? endo[NIT - 1u] : endo[0]);
+      }
+      const bool both = single[0] && single[NIT - 1u];     // a lane owning two such columns: rare
+      if (__any(both)) single_col(both, bad_[NIT - 1u], cidx_[NIT - 1u], pv[NIT - 1u], endo[NIT - 1u]);
     }
-    const bool both = single[0] && single[1];            // a lane owning two such columns: rare
-    if (__any(both)) single_col(both, bad_[1], cidx_[1], pv[1], endo[1]);
   }
 
   // the trailing 1-2 sites of an alignment whose length is not a multiple of 3 never form a

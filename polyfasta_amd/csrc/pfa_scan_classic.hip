@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   // per-lane partial sums of this chunk
   uint32_t acc_S = 0u, acc_bad = 0u;
   unsigned long long acc_H = 0ull;
-  CodonPass<BITMAPS> cp;
+  CodonPass<BITMAPS, TWP == 128> cp;   // 128-site tiles: the two lane groups share the codon columns out
   if constexpr (HAS_CDS) cp.init(lane, unit, synhist, A, D, G::LPG - 1u);
 
   const uint8_t* const mat = A.bases + D.base_off;
@@ -162,13 +162,18 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
 #pragma unroll
     for (uint32_t b = 0; b < 4u; ++b) {
       const uint32_t off = 4u * jl + b;
-      const bool pb = ((vd >> (8u * b)) & 0xFFu) != 0u && off < lim && rg == 0u;
+      const bool varies = ((vd >> (8u * b)) & 0xFFu) != 0u && off < lim;   // the same in every lane group
+      const bool pb = varies && rg == 0u;
       const uint64_t m = __ballot(pb);
-      if (pb) {
-        const uint32_t i = P + mbcnt64(m);
-        const uint32_t ent = off | ((vd >> (8u * b)) & 0xFFu) << 8;
-        if (wide_list) list32[i] = ent;
-        else list16[i] = uint16_t(ent);
+      if (varies) {
+        // position in the list: variable sites of lower lanes of group 0 (the twin lanes of the other
+        // groups note it too: the coding pass of 128-site tiles runs on both)
+        const uint32_t i = P + (uint32_t)__popcll(m & ((1ull << jl) - 1ull));
+        if (pb) {
+          const uint32_t ent = off | ((vd >> (8u * b)) & 0xFFu) << 8;
+          if (wide_list) list32[i] = ent;
+          else list16[i] = uint16_t(ent);
+        }
         if constexpr (HAS_CDS) idx4 |= i << (8u * b);
       }
       if constexpr (BITMAPS)
@@ -278,7 +283,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       // ... and, per lane, of the sites of this lane and the one before it (every lane active)
       const unsigned long long idx8 = (unsigned long long)wave_shr1(idx4) | (unsigned long long)idx4 << 32;
       auto hget_lane = [&](int rel) -> HMask<uint32_t> {
-        const uint32_t k = (uint32_t)(rel - (4 * (int)lane - 4)) & 7u;
+        const uint32_t k = (uint32_t)(rel - (4 * (int)jl - 4)) & 7u;
         return list_hmask(rel < 0 ? rel : (int)((uint32_t)(idx8 >> (8u * k)) & 0xFFu));
       };
       // columns with two or three variable positions: one row per lane out of the LDS tile; the one or
