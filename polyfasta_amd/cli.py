@@ -565,20 +565,20 @@ def main(argv=None, comm=None):
             parser.error(parser.print_help())
     if len(args.file) != 0 and args.dir != ".":                                    # :90-91
         parser.error("Run with either --file/-f or --dir/-d, but not both")
-    elif len(args.file) == 0 and args.dir != ".":                                  # :93-94
+    from . import _lib, dist
+    if comm is None and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU: start them now, before anything here has touched the GPU or the files
+        return dist.spawn_ranks(args.gpus, [sys.executable, "-m", "polyfasta_amd"] + list(sys.argv[1:] if argv is None else argv))
+    if len(args.file) == 0 and args.dir != ".":                                    # :93-94
         args.file = [args.dir + "/" + i for i in os.listdir(args.dir)]
     elif len(args.file) == 0 and args.dir == "." and args.pipe:                    # :96-100
         args.file = ["stdin"] if not args.name else [args.name]
     if len(args.file) > 0 and args.pipe and not (args.file[0] == "stdin" or args.file[0] == args.name):
         parser.error("A FASTA file or multiple files cannot be used with the --pipe argument.")   # :105-106
 
-    from . import _lib, dist
     rank, _, world = dist.env_world()
     if comm is not None:
         rank, world = comm.rank, comm.world
-    elif args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # one process per GPU: start them now, before anything here has touched the GPU
-        return dist.spawn_ranks(args.gpus, [sys.executable, "-m", "polyfasta_amd"] + list(sys.argv[1:] if argv is None else argv))
     elif args.gpus > 1 and world != args.gpus:
         print(f"polyfasta_amd: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         return 2

@@ -155,3 +155,26 @@ def test_work_queue_hands_out_every_item_once(tmp_path):
     assert all(len(json.load(open(tmp_path / f"got{r}"))) > 0 for r in range(4))       # nobody starved
     first = min(claims, key=lambda c: -sizes[c[0]])
     assert sizes[first[0]] == max(sizes)                                                # the largest files go first
+
+
+def test_bench_and_cli_gpus_flag_never_fall_back_silently(tmp_path):
+    """`--gpus 2` where the GPUs are missing (this container has none): non-zero exit and no JSON line / no
+    rows on stdout — never a silent run on fewer GPUs"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "4"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and '"n_gpus"' not in p.stdout, (p.returncode, p.stdout[-300:])
+    fa = tmp_path / "a.fa"
+    fa.write_text(">x\\nACGT\\n>y\\nACGA\\n")
+    p = subprocess.run([sys.executable, "-m", "polyfasta_amd", "-f", str(fa), "--gpus", "2"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "a.fa," not in p.stdout, (p.returncode, p.stdout[-300:])
+
+
+def test_cli_gpus_flag_starts_the_ranks_with_the_same_arguments(monkeypatch):
+    from polyfasta_amd import cli, dist
+    seen = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(dist, "spawn_ranks", lambda n, argv, timeout=None: seen.update(n=n, argv=argv) or 0)
+    assert cli.main(["-d", "somedir", "--cds", "--gpus", "8", "-o", "out.csv"]) == 0
+    assert seen["n"] == 8 and seen["argv"][1:3] == ["-m", "polyfasta_amd"]
+    assert seen["argv"][3:] == ["-d", "somedir", "--cds", "--gpus", "8", "-o", "out.csv"]
