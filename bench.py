@@ -110,7 +110,10 @@ class Workload:
         ach = self.alg_bytes / (avg * 1e-3) / 1e9
         return {"workload": self.label(), "kernel": self.plan.description, "launches_per_run": self.plan.n_launches,
                 "kernel_ms_avg": avg, "kernel_ms_min": float(kms.min()), "algorithmic_bytes_per_launch": self.alg_bytes,
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "frac_of_measured_copy_6290": ach / 6290.0,
+                # scan units (alignment x population = CSV rows) per second of kernel time
+                "alignments_per_s_kernel": self.B * self.K / (avg * 1e-3), "site_columns_per_s_kernel": self.B * self.K * self.L / (avg * 1e-3)}
 
     def close(self):
         self.plan.close()
