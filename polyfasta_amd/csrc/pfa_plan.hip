@@ -318,6 +318,15 @@ void pfa_plan_destroy(pfa_plan* p) {
     pool.give(false, p->d_var_bm, p->cap_var);
     pool.give(false, p->d_syn_bm, p->cap_syn);
     pool.give(false, p->d_non_bm, p->cap_non);
+  } else {   // the context is gone (pfa_shutdown() before the plan): nothing to pool, just release
+    (void)hipFree(p->d_descs);
+    (void)hipFree(p->d_row_idx);
+    (void)hipFree(p->d_unit_ids);
+    (void)hipFree(p->d_slab);
+    if (p->h_slab) (void)hipHostFree(p->h_slab);
+    (void)hipFree(p->d_var_bm);
+    (void)hipFree(p->d_syn_bm);
+    (void)hipFree(p->d_non_bm);
   }
   for (int i = 0; i < pfa::kEventRing; ++i) {
     if (p->ev0[i]) (void)hipEventDestroy(p->ev0[i]);

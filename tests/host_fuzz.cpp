@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <string>
+#include <sys/stat.h>
 #include <vector>
 
 #include "../include/pfa.h"
@@ -91,11 +92,15 @@ static void fuzz_text(const std::string& s) {
 
 static void fuzz_files(const char* dir) {
   const uint32_t nf = 1 + below(12);
-  std::vector<std::string> paths;
+  std::vector<std::string> paths, made_dirs;
   for (uint32_t i = 0; i < nf; ++i) {
     std::string p = std::string(dir) + "/f" + std::to_string(i) + ".fa";
     if (below(10) == 0) p += ".missing";
-    else {
+    else if (below(12) == 0) {      // a sub-directory among the files: not a regular file -> PFA_ERR_IO, no abort
+      p += ".dir";
+      mkdir(p.c_str(), 0700);
+      made_dirs.push_back(p);
+    } else {
       FILE* f = fopen(p.c_str(), "wb");
       std::string s;
       if (below(3) == 0) s = random_fasta();
@@ -124,7 +129,13 @@ static void fuzz_files(const char* dir) {
   if (used > cap) { fprintf(stderr, "load_files used %llu > cap %llu\n", (unsigned long long)used, (unsigned long long)cap); abort(); }
   free(names);
   free(bases);
+  for (uint32_t i = 0; i < nf; ++i)
+    if (paths[i].size() > 4 && paths[i].compare(paths[i].size() - 4, 4, ".dir") == 0 && info[i].status != PFA_ERR_IO) {
+      fprintf(stderr, "a directory was not reported as PFA_ERR_IO (status %d)\n", info[i].status);
+      abort();
+    }
   for (auto& p : paths) unlink(p.c_str());
+  for (auto& p : made_dirs) rmdir(p.c_str());
 }
 
 static void fuzz_rows() {

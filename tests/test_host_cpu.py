@@ -316,3 +316,32 @@ def test_native_cds_rows_match_python_rows():
     with redirect_stdout(buf):
         cli.emit(events, cli.Sink("", True), True, True)
     assert buf.getvalue() == "".join(cli.format_cds_row(u[0], u[1], u[2], u[3], u[4], u[5], True) + "\n" for u in units[:500])
+
+
+def test_batch_loader_survives_anything_on_the_path_list(tmp_path):
+    """a sub-directory of --dir, a missing file, a file with non-ASCII sequence bytes: each gets
+    its own status, the regular files of the same call are packed, nothing aborts or throws across the ABI;
+    UTF-8 sample names are kept"""
+    good = tmp_path / "good.fa"
+    good.write_text(">a\nACGT\n>b\nACGA\n")
+    utf = tmp_path / "utf8_name.fa"
+    utf.write_bytes(">muestra_ñ\nACGT\n>próxima\nTCGT\n".encode("utf-8"))
+    bad = tmp_path / "bad_seq.fa"
+    bad.write_bytes(b">a\nAC\xc3\xb1T\n>b\nACGTT\n")
+    sub = tmp_path / "subdir"
+    sub.mkdir()
+    paths = [str(good), str(sub), str(tmp_path / "missing.fa"), str(bad), str(utf)]
+    buf = np.zeros(1 << 16, dtype=np.uint8)
+    info, names, used = fasta.load_files(paths, buf, stride_align=128, want_names=True, threads=3)
+    st = info["status"].tolist()
+    assert st == [0, _lib.PFA_ERR_IO, _lib.PFA_ERR_IO, _lib.PFA_FILE_UNSUPPORTED, 0]
+    assert names[4] == ["muestra_ñ", "próxima"]
+    for k in (0, 4):
+        fi = info[k]
+        m = buf[int(fi["base_off"]):int(fi["base_off"]) + 2 * int(fi["row_stride"])].reshape(2, -1)[:, :4]
+        assert bytes(m[0]) in (b"ACGT",) and bytes(m[1]) in (b"ACGA", b"TCGT")
+    # the direct entry points answer with codes too
+    raw = np.frombuffer(bad.read_bytes(), dtype=np.uint8)
+    with pytest.raises(_lib.PfaError) as e:
+        fasta.parse_fasta_bytes(raw)
+    assert e.value.code == _lib.PFA_ERR_UNSUPPORTED
