@@ -171,11 +171,12 @@ int pfa_comm_all_gather(const void* send_host, void* recv_host, size_t bytes_per
   if (bytes_per_rank == 0) return PFA_OK;
   if (!send_host || !recv_host) { pfa::set_error("pfa_comm_all_gather: NULL buffer"); return PFA_ERR_ARG; }
   const size_t w = (size_t)g_comm.world;
-  int rc = need_stage((w + 1) * bytes_per_rank);
+  const size_t send_span = (bytes_per_rank + 255u) & ~size_t(255);   // the receive buffer starts on a 256-byte boundary
+  int rc = need_stage(send_span + w * bytes_per_rank);
   if (rc != PFA_OK) return rc;
   hipStream_t st = pfa::ctx().stream;
   uint8_t* d_send = g_comm.d_stage;
-  uint8_t* d_recv = g_comm.d_stage + bytes_per_rank;
+  uint8_t* d_recv = g_comm.d_stage + send_span;
   PFA_HIP(hipMemcpyAsync(d_send, send_host, bytes_per_rank, hipMemcpyHostToDevice, st));
   PFA_NCCL(g_comm.api.AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, g_comm.comm, st));
   PFA_HIP(hipMemcpyAsync(recv_host, d_recv, w * bytes_per_rank, hipMemcpyDeviceToHost, st));
