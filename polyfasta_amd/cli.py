@@ -213,7 +213,10 @@ def _events_for(fidx, path, name, status, names, n_rows, seqlen, args, add_unit)
         evs.append((fidx, "unit", add_unit(None), name, "NA", n_rows, seqlen))
     else:
         for pop in args.pops.split(","):                                           # :123-134
-            rows = [i for i, h in enumerate(names) if pop in h]
+            # header names arrive as bytes from the native loader (str from the --pipe parser):
+            # substring match on the same kind
+            key = pop.encode("utf-8", "surrogateescape") if names and isinstance(names[0], bytes) else pop
+            rows = [i for i, h in enumerate(names) if key in h]
             if len(rows) == 0:
                 evs.append((fidx, "comment", f"# Pop {pop} string was not found in fasta headers."))
                 continue
@@ -331,25 +334,32 @@ def process_files(indexed_paths, args, more=None):
                     pending += _events_for(fidx, path, path.split("/")[-1], st, None, fi[1], fi[2], args,
                                            lambda rows, k=k: unit_of[k])
             else:
-                dl, rl = [], []
-                for k, fi in enumerate(info):
-                    st = int(fi["status"])
+                # one unit per (file, population): descriptor columns collected as Python lists, the table
+                # built once per batch
+                cols = {f: [] for f in ("base_off", "n_sites", "row_stride", "mat_rows", "n_rows", "row_idx_off")}
+                rl, nri = [], [0]
+                for k, fi in enumerate(info.tolist()):
+                    st = fi[0]
                     if st == PFA_FILE_DEFERRED:
                         continue
                     fidx, path = chunk[k]
 
                     def add_unit(rows, fi=fi):
-                        d = np.zeros(1, dtype=DESC_DTYPE)[0]
-                        d["base_off"], d["n_sites"], d["row_stride"], d["mat_rows"] = fi["base_off"], fi["n_sites"], fi["row_stride"], fi["n_rows"]
-                        d["flags"] = PFA_FLAG_CDS if args.cds else 0
-                        d["n_rows"], d["row_idx_off"] = len(rows), sum(len(r) for r in rl)
-                        rl.append(np.asarray(rows, dtype=np.uint32))
-                        dl.append(d)
-                        return len(dl) - 1
-                    pending += _events_for(fidx, path, path.split("/")[-1], st, names[k], int(fi["n_rows"]),
-                                           int(fi["n_sites"]), args, add_unit)
-                descs = np.array(dl, dtype=DESC_DTYPE) if dl else []
-                ridx = np.concatenate(rl) if rl else None
+                        cols["base_off"].append(fi[4])
+                        cols["n_sites"].append(fi[2])
+                        cols["row_stride"].append(fi[3])
+                        cols["mat_rows"].append(fi[1])
+                        cols["n_rows"].append(len(rows))
+                        cols["row_idx_off"].append(nri[0])
+                        nri[0] += len(rows)
+                        rl.append(rows)
+                        return len(rl) - 1
+                    pending += _events_for(fidx, path, path.split("/")[-1], st, names[k], fi[1], fi[2], args, add_unit)
+                descs = np.zeros(len(rl), dtype=DESC_DTYPE)
+                for f, v in cols.items():
+                    descs[f] = v
+                descs["flags"] = PFA_FLAG_CDS if args.cds else 0
+                ridx = np.fromiter((r for rows in rl for r in rows), dtype=np.uint32, count=nri[0]) if rl else None
             if len(descs):
                 out = _scan_uploaded(dev, used, descs, ridx)
             else:

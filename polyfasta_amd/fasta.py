@@ -79,7 +79,7 @@ def load_files(paths, bases_out: np.ndarray, stride_align: int = 128, want_names
     """Native multi-threaded ingest of many files into `bases_out` (uint8 buffer).
     Returns (info FILE_INFO_DTYPE[len(paths)], names or None, bytes_used).
     info.status == PFA_FILE_DEFERRED marks files that did not fit this call's
-    buffer.  `names[i]` is the list of record names of file i (want_names)."""
+    buffer.  `names[i]` is the list of record names of file i, as bytes (want_names)."""
     import ctypes
     import os
     lib = _lib.load()
@@ -94,15 +94,19 @@ def load_files(paths, bases_out: np.ndarray, stride_align: int = 128, want_names
                                         ctypes.byref(used), ctypes.byref(nused)))
     names = None
     if want_names:
+        # header names of file i: k NUL-terminated byte strings from names_off[i]; the files' name blocks
+        # sit back to back in arbitrary order, so a block ends where the next one (by offset) begins.
+        # They stay bytes: --pops matches substrings on them without decoding 100 k x N headers.
         raw = names_buf[:nused.value].tobytes()
+        rec = info.tolist()
+        live = sorted((fi[5], i) for i, fi in enumerate(rec) if fi[1] and fi[0] != _lib.PFA_FILE_DEFERRED)
+        ends = {i: (live[j + 1][0] if j + 1 < len(live) else len(raw)) for j, (_, i) in enumerate(live)}
         names = []
-        for fi in info:
-            k = int(fi["n_rows"])
-            if k == 0 or int(fi["status"]) == _lib.PFA_FILE_DEFERRED:
+        for i, fi in enumerate(rec):
+            if i not in ends:
                 names.append([])
                 continue
-            o = int(fi["names_off"])
-            names.append([p.decode("utf-8", "surrogateescape") for p in raw[o:].split(b"\0", k)[:k]])
+            names.append(raw[fi[5]:ends[i]].split(b"\0")[:fi[1]])
     return info, names, used.value
 
 

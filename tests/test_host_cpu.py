@@ -335,7 +335,7 @@ def test_batch_loader_survives_anything_on_the_path_list(tmp_path):
     info, names, used = fasta.load_files(paths, buf, stride_align=128, want_names=True, threads=3)
     st = info["status"].tolist()
     assert st == [0, _lib.PFA_ERR_IO, _lib.PFA_ERR_IO, _lib.PFA_FILE_UNSUPPORTED, 0]
-    assert names[4] == ["muestra_ñ", "próxima"]
+    assert [n.decode("utf-8") for n in names[4]] == ["muestra_ñ", "próxima"] and names[0] == [b"a", b"b"] and names[1] == []
     for k in (0, 4):
         fi = info[k]
         m = buf[int(fi["base_off"]):int(fi["base_off"]) + 2 * int(fi["row_stride"])].reshape(2, -1)[:, :4]
