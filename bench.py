@@ -336,7 +336,15 @@ def main():
     lib = _lib.load()
     try:
         _lib.init()                               # GPU LOCAL_RANK; fails loudly when it is not there
-        comm = dist.RcclComm() if (world > 1 or os.environ.get("PFA_FORCE_DIST")) else None   # PFA_FORCE_DIST: 1-rank RCCL rehearsal
+        comm = None
+        if world > 1 or os.environ.get("PFA_FORCE_DIST"):       # PFA_FORCE_DIST: 1-rank RCCL rehearsal
+            factory = os.environ.get("PFA_COMM_FACTORY")         # tests only ("module:Class"): ranks sharing one GPU cannot use RCCL
+            if factory:
+                import importlib
+                mod, cls = factory.split(":")
+                comm = getattr(importlib.import_module(mod), cls)()
+            else:
+                comm = dist.RcclComm()
     except (_lib.PfaError, TimeoutError) as e:
         print(f"bench.py: rank {rank} of {world}: {e} (one process per GPU: --gpus must not exceed the visible GPUs)", file=sys.stderr)
         sys.exit(2)
@@ -394,7 +402,7 @@ def main():
                                    + hw.label() + f" per GPU per step, theta={args.theta}",
                        "rows": N, "sites": L, "batch_per_gpu": B, "row_stride": hw.stride,
                        "parallelism": f"independent alignments sharded over {world} rank(s), one process per GPU; one RCCL "
-                                      f"all-gather of the result records (pfa_comm_all_gather_results)" if world > 1 else "single GPU",
+                                      f"all-gather of the result records ({type(comm).__name__})" if world > 1 else "single GPU",
                        "kernel_variant": {0: "lds_dma_nt", 2: "lds_dma_default_policy"}[args.variant],
                        "tiles_per_chunk": plan.tiles_per_chunk, "lds_bytes_per_wave": plan.lds_bytes,
                        "rows_per_chunk": plan.rows_per_chunk, "tile_width": plan.tile_width},

@@ -13,7 +13,9 @@ class GlooComm(dist.Comm):
     def __init__(self):
         self.rank, self.local_rank, self.world = dist.env_world()
         if not td.is_initialized():
-            td.init_process_group(backend="gloo")
+            with dist.stdout_to_stderr():        # gloo announces its peers on stdout
+                td.init_process_group(backend="gloo")
+                td.barrier()
 
     def barrier(self):
         td.barrier()
@@ -28,6 +30,15 @@ class GlooComm(dist.Comm):
         recv = torch.empty(self.world * send.numel(), dtype=torch.uint8)
         td.all_gather_into_tensor(recv, send)
         return recv.numpy().reshape(self.world, -1)
+
+    def all_gather_plan_results(self, plan):
+        """what RcclComm does on the device, through the host: the records of the plan's last run, of every rank"""
+        import ctypes
+        from polyfasta_amd import _lib
+        ptr, nbytes = plan.results_dev()
+        local = np.empty(nbytes, dtype=np.uint8)
+        _lib.check(_lib.load().pfa_download(_lib.ptr(local), ctypes.c_void_p(ptr), nbytes))
+        return self.all_gather_fixed(local).view(_lib.RESULT_DTYPE).reshape(self.world, -1)
 
     def close(self):
         if td.is_initialized():

@@ -113,3 +113,20 @@ def test_cli_through_rccl_with_one_rank(gpu, tmp_path):
     p = subprocess.run([sys.executable, "-m", "polyfasta_amd"] + argv, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     assert p.stdout == want
+
+
+def test_bench_with_two_ranks_on_one_gpu(gpu):
+    """bench.py --gpus 2 end to end on the one GPU (its own launcher, both ranks on GPU 0, a gloo communicator
+    injected because RCCL refuses two ranks per device): ONE JSON line, n_gpus 2, the records of both ranks
+    gathered, rank 0's share equal to its own fetch"""
+    import json
+    env = dict(os.environ, PFA_ALLOW_SHARED_GPU="1", PFA_COMM_FACTORY="tests._gloo_comm:GlooComm", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "512"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3
+    assert j["check"]["gathered_records"] == 2 * 512 and j["check"]["gathered_rank0_equals_fetch"] is True
+    assert j["value"] > 0 and "cpu_baseline" not in j and "workloads" not in j
