@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 3
+#define PFA_ABI_VERSION 4
 
 /* error codes */
 #define PFA_OK 0
@@ -207,6 +207,12 @@ int pfa_comm_all_reduce_max(double* x);     /* in place; e.g. the slowest rank's
 /* `bytes_per_rank` bytes from every rank, in rank order, to every rank (host buffers,
  * staged through device memory; recv_host holds world x bytes_per_rank) */
 int pfa_comm_all_gather(const void* send_host, void* recv_host, size_t bytes_per_rank);
+/* variable-size gather to ONE rank (the CLI's final gather: only rank 0 prints): rank r sends
+ * counts[r] bytes (every rank passes the same `counts`, e.g. from a one-word
+ * pfa_comm_all_gather); the root receives them back to back in rank order in recv_host
+ * (sum of counts; ignored elsewhere).  ncclSend / ncclRecv: nothing travels to a rank that
+ * does not need it, nothing is padded. */
+int pfa_comm_gatherv(const void* send_host, uint64_t send_bytes, void* recv_host, const uint64_t* counts, int root);
 /* the result records of the plan's last run, of every rank, straight from device
  * memory (no host round trip before the collective); every rank's plan must hold
  * the same number of units; out: world x n_desc records; call it before
@@ -272,6 +278,21 @@ int pfa_fasta_pack(const uint8_t* text, uint64_t n_text, const pfa_fasta_rec* re
                    uint8_t* bases_out, uint32_t row_stride);
 
 
+/* The same records in ONE pass, for texts that may be modified: every record's
+ * sequence comes back as one contiguous run [seq_off, seq_off + seq_len) of RAW
+ * bytes (not upper-cased; bytes >= 0x80 not looked at) — records written on
+ * several lines are compacted in place.  This is what the streaming ingest below
+ * does to a file in its pinned ring; upper-casing is left to the card.  Returns
+ * the record count, PFA_ERR_FORMAT for "not FASTA", PFA_ERR_ARG when cap is too
+ * small (the text may have been modified by then). */
+typedef struct pfa_fasta_row {
+  uint64_t name_off; /* into text: header without '>' and trailing whitespace */
+  uint32_t name_len;
+  uint32_t seq_len;
+  uint64_t seq_off;  /* into text (after the call) */
+} pfa_fasta_row;
+int64_t pfa_fasta_index_compact(uint8_t* text, uint64_t n_text, pfa_fasta_row* rows, uint64_t cap);
+
 /* Batch loader: read, index and pack `n_files` FASTA files with `n_threads`
  * host threads (0 = 16) into `bases_out` (capacity `cap` bytes); matrices are
  * 256-byte aligned, placed in arbitrary order (info[i].base_off), row stride =
@@ -327,6 +348,89 @@ int64_t pfa_format_cds_rows(const char* name_blob, const uint64_t* name_off, con
 /* repr(float) of CPython 3 into out32 (at least 32 bytes, not NUL-terminated);
  * returns the length */
 int pfa_format_double(double x, char* out32);
+
+/* ---- streaming ingest: files -> device-resident matrices -> launched plans -----
+ * The feeder of the scan for the reference's file loop (PolyFastA.py:104-140,
+ * readfasta :227-250, population split :122-134), built so that the PCIe link is
+ * the only thing a directory of alignments waits for:
+ *   loader threads   read() each file ONCE, straight into a ring of pinned slots,
+ *                    index it in place (pfa_fasta_index_compact) and match the
+ *                    --pops keys against its record names;
+ *   uploader thread  copies every slot to the card as soon as its files have
+ *                    landed (own HIP stream, at most two copies in flight);
+ *   the caller       (pfa_ingest_next) takes whatever has been uploaded, lets the
+ *                    card turn the raw text into row-major upper-case matrices
+ *                    (repack_kernel: one pass at HBM speed), builds the scan plan
+ *                    of those files and launches it.
+ * Files are handed out in feed order, so batches are consecutive runs of it.
+ * Nothing here scans on the CPU. */
+typedef struct pfa_ingest pfa_ingest;
+typedef struct pfa_ingest_opts {
+  uint32_t n_threads;     /* loader threads; 0 = min(16, CPUs of this process / local ranks) */
+  uint32_t stride_align;  /* row stride = round_up(n_sites, stride_align); 0 = 128 */
+  uint32_t unit_flags;    /* PFA_FLAG_CDS or 0: flags of every scan unit */
+  uint32_t n_keys;        /* --pops keys (0: one unit per file) */
+  const char* const* keys;/* NUL-terminated byte strings, matched as substrings of the record names */
+  uint64_t slot_bytes;    /* size of a pinned slot = one H2D copy; 0 = 64 MiB (less for small inputs) */
+  uint32_t n_slots;       /* pinned slots; 0 = 4 */
+  uint32_t reserved;
+} pfa_ingest_opts;
+
+#define PFA_NO_KEY 0xFFFFFFFFu
+#define PFA_BATCH_REGULAR 1u /* every file packed, every key found, coding lengths multiples of 3 */
+
+/* One batch = a run of consecutive files of the feed order.  Every pointer is owned
+ * by the ingest and valid until the next pfa_ingest_next() / pfa_ingest_close(). */
+typedef struct pfa_ingest_batch {
+  uint32_t n_files;
+  uint32_t n_units;          /* scan units = CSV rows */
+  uint32_t first_pos;        /* feed position of the batch's first file */
+  uint32_t flags;            /* PFA_BATCH_* */
+  const uint32_t* file_idx;  /* [n_files] index into the `paths` of pfa_ingest_open() */
+  const int32_t* status;     /* [n_files] 0 = packed, PFA_FILE_NOT_FASTA, PFA_FILE_UNEQUAL, PFA_ERR_IO */
+  const uint32_t* n_rows;    /* [n_files] records */
+  const uint32_t* n_sites;   /* [n_files] alignment length (status 0) */
+  const uint32_t* key_rows;  /* [n_files x n_keys] records whose name holds key k (0: "not found") */
+  const uint32_t* unit_file; /* [n_units] file of the unit, as an index into THIS batch's arrays */
+  const uint32_t* unit_key;  /* [n_units] key index, PFA_NO_KEY without --pops */
+  const uint32_t* unit_rows; /* [n_units] N of the unit */
+  const uint32_t* bad_bytes; /* [n_files] nonzero once the plan has been fetched: bytes >= 0x80 in
+                                sequence lines (that file is PFA_FILE_UNSUPPORTED) */
+  pfa_plan* plan;            /* already launched; NULL when n_units == 0; owned by the ingest */
+} pfa_ingest_batch;
+
+/* `paths`: every file the job may read (kept: names for the rows).  Nothing is read
+ * before pfa_ingest_feed(). */
+int pfa_ingest_open(const char* const* paths, uint32_t n_files, const pfa_ingest_opts* opts, pfa_ingest** out);
+/* append files (indices into `paths`; NULL = 0..n-1) to the feed order; `last` != 0: no
+ * further feed follows (a multi-GPU rank feeds what it claims from the shared queue) */
+int pfa_ingest_feed(pfa_ingest* ing, const uint32_t* file_idx, uint32_t n, int last);
+/* files fed but not yet handed out in a batch */
+uint32_t pfa_ingest_backlog(const pfa_ingest* ing);
+/* blocks until at least one uploaded slot is there; 1 = batch, 0 = every fed file has been
+ * handed out and the last feed was marked `last`, < 0 = error */
+int pfa_ingest_next(pfa_ingest* ing, pfa_ingest_batch* out);
+/* [0] seconds the loader threads spent in read(), [1] in the index pass, [2] bytes read,
+ * [3] seconds the uploader had copies in flight, [4] bytes copied, [5] loader threads,
+ * [6] seconds in repack launches + plan creation, [7] batches */
+int pfa_ingest_stats(const pfa_ingest* ing, double* out8);
+/* display names (the text after the last '/', PolyFastA.py:110) of every path of
+ * pfa_ingest_open(): name f = blob[off[f] .. off[f+1]); owned by the ingest */
+int pfa_ingest_names(const pfa_ingest* ing, const char** blob, const uint64_t** off);
+void pfa_ingest_close(pfa_ingest* ing);
+
+/* CSV rows of units named by index: row i is file `file_idx[i]` (name =
+ * names_blob[names_off[f] .. names_off[f+1])), population key `key[i]` (PFA_NO_KEY:
+ * "NA").  coding == 0: the 8-column row (pfa_format_plain_rows), else the 14-column
+ * one (pfa_format_cds_rows; syn_num: PFA_SYN_BINS words per row).  Same return
+ * convention as those two. */
+int64_t pfa_format_rows_indexed(const char* names_blob, const uint64_t* names_off,
+                                const char* keys_blob, const uint64_t* keys_off,
+                                uint32_t n, const uint32_t* file_idx, const uint32_t* key,
+                                const uint32_t* n_rows, const uint32_t* n_sites,
+                                const pfa_result* res, const uint32_t* syn_num,
+                                const double* a1, const double* e1, const double* e2, int jc, int coding,
+                                char* out, uint64_t cap, int64_t* bad_row);
 
 /* pinned (page-locked) host memory for the ingest buffer: pre-faulted, and H2D
  * from it runs at the PCIe rate */

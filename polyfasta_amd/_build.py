@@ -11,9 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ_DIR = os.path.join(CSRC, "build")
 LIB_PATH = os.environ.get("PFA_LIB") or os.path.join(_HERE, "libpfa_hip.so")
-SOURCES = ["pfa_scan_classic.hip", "pfa_scan_tall.hip", "pfa_plan.hip", "pfa_synth.hip", "pfa_comm.cpp",
+SOURCES = ["pfa_scan_classic.hip", "pfa_scan_tall.hip", "pfa_plan.hip", "pfa_synth.hip", "pfa_ingest.hip", "pfa_comm.cpp",
            "pfa_fasta.cpp", "pfa_format.cpp"]
-HEADERS = ["pfa_codon.h", "pfa_common.h", "pfa_kernels.h", "pfa_launch.h", "pfa_layout.h",
+HEADERS = ["pfa_codon.h", "pfa_common.h", "pfa_host.h", "pfa_kernels.h", "pfa_launch.h", "pfa_layout.h",
            os.path.join("..", "..", "include", "pfa.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fconstexpr-steps=500000000", "-Wall",
           "-Wno-unused-function"]
@@ -57,27 +57,29 @@ def build(force=False, verbose=False, extra_flags=(), lib_path=None):
     os.makedirs(OBJ_DIR, exist_ok=True)
     t_hdr = _newest_header()
     hipcc = _hipcc()
-    tag = "" if not extra_flags else "." + str(abs(hash(tuple(extra_flags))) % 10 ** 8)
+    import hashlib
+    tag = "" if not extra_flags else "." + hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8]
+    tmp = f".{os.getpid()}.tmp"      # two builds at once (two ranks, two tools) never share a temporary
 
     def compile_one(src):
         o = _obj(src) if not tag else _obj(src)[:-2] + tag + ".o"
         if not (force or extra_flags) and not _obj_stale(src, t_hdr):
             return o
         lang = ["-x", "hip"] if src.endswith(".hip") else []
-        cmd = [hipcc] + CFLAGS + list(extra_flags) + ["-c"] + lang + ["-o", o + ".tmp", os.path.join(CSRC, src)]
+        cmd = [hipcc] + CFLAGS + list(extra_flags) + ["-c"] + lang + ["-o", o + tmp, os.path.join(CSRC, src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        os.replace(o + ".tmp", o)
+        os.replace(o + tmp, o)
         return o
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc] + LDFLAGS + ["-o", out + ".tmp"] + objs
+    cmd = [hipcc] + LDFLAGS + ["-o", out + tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(out + ".tmp", out)
+    os.replace(out + tmp, out)
     return out
 
 

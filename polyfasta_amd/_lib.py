@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PFA_LIB") or os.path.join(_HERE, "libpfa_hip.so")   # PFA_LIB: timing experiments with other builds
 
-PFA_ABI_VERSION = 3
+PFA_ABI_VERSION = 4
 PFA_NO_ROW_IDX = 0xFFFFFFFF
 PFA_FLAG_CDS = 1
 PFA_WANT_VAR_BITMAP = 1
@@ -24,6 +24,8 @@ PFA_MAX_ROWS = 1 << 20
 PFA_MAX_ROWS_CDS = PFA_MAX_ROWS
 PFA_COMM_ID_BYTES = 128
 PFA_ERR_FORMAT = -7
+PFA_NO_KEY = 0xFFFFFFFF
+PFA_BATCH_REGULAR = 1
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -54,7 +56,8 @@ PFA_FILE_DEFERRED = 3
 PFA_FILE_UNSUPPORTED = 4
 PFA_ERR_IO = -8
 PFA_ERR_UNSUPPORTED = -9
-assert FILE_INFO_DTYPE.itemsize == 32
+FASTA_ROW_DTYPE = np.dtype([("name_off", "<u8"), ("name_len", "<u4"), ("seq_len", "<u4"), ("seq_off", "<u8")], align=True)
+assert FILE_INFO_DTYPE.itemsize == 32 and FASTA_ROW_DTYPE.itemsize == 24
 assert DESC_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 56 and FASTA_REC_DTYPE.itemsize == 32
 
 
@@ -63,6 +66,19 @@ class SynthParamsC(ctypes.Structure):
                 ("n_rows", ctypes.c_uint32), ("n_sites", ctypes.c_uint32), ("row_stride", ctypes.c_uint32),
                 ("seg_thresh", ctypes.c_uint32), ("tri_thresh", ctypes.c_uint32), ("n_units", ctypes.c_uint32),
                 ("coding", ctypes.c_uint32)]
+
+
+class IngestOptsC(ctypes.Structure):
+    _fields_ = [("n_threads", ctypes.c_uint32), ("stride_align", ctypes.c_uint32), ("unit_flags", ctypes.c_uint32),
+                ("n_keys", ctypes.c_uint32), ("keys", ctypes.POINTER(ctypes.c_char_p)), ("slot_bytes", ctypes.c_uint64),
+                ("n_slots", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+class IngestBatchC(ctypes.Structure):
+    _fields_ = [("n_files", ctypes.c_uint32), ("n_units", ctypes.c_uint32), ("first_pos", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+                ("file_idx", u32p), ("status", ctypes.POINTER(ctypes.c_int32)), ("n_rows", u32p), ("n_sites", u32p),
+                ("key_rows", u32p), ("unit_file", u32p), ("unit_key", u32p), ("unit_rows", u32p), ("bad_bytes", u32p),
+                ("plan", ctypes.c_void_p)]
 
 
 class PfaLibraryError(RuntimeError):
@@ -127,6 +143,16 @@ _PROTOTYPES = {
     "pfa_fasta_pack": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint64, _vp, ctypes.c_uint32]),
     "pfa_fasta_load_files": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp,
                                             ctypes.c_uint64, _vp, _vp, ctypes.c_uint64, u64p, u64p]),
+    "pfa_fasta_index_compact": (ctypes.c_int64, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint64]),
+    "pfa_ingest_open": (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, ctypes.POINTER(IngestOptsC), ctypes.POINTER(_vp)]),
+    "pfa_ingest_feed": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_int]),
+    "pfa_ingest_backlog": (ctypes.c_uint32, [_vp]),
+    "pfa_ingest_next": (ctypes.c_int, [_vp, ctypes.POINTER(IngestBatchC)]),
+    "pfa_ingest_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double)]),
+    "pfa_ingest_names": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "pfa_ingest_close": (None, [_vp]),
+    "pfa_format_rows_indexed": (ctypes.c_int64, [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                 ctypes.c_int, ctypes.c_int, _vp, ctypes.c_uint64, _vp]),
     "pfa_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "pfa_host_free": (ctypes.c_int, [_vp]),
     "pfa_comm_unique_id": (ctypes.c_int, [_vp]),
@@ -137,6 +163,7 @@ _PROTOTYPES = {
     "pfa_comm_all_reduce_max": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double)]),
     "pfa_comm_all_gather": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t]),
     "pfa_comm_all_gather_results": (ctypes.c_int, [_vp, _vp]),
+    "pfa_comm_gatherv": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, _vp, ctypes.c_int]),
     "pfa_comm_destroy": (ctypes.c_int, []),
 }
 

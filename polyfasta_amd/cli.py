@@ -25,32 +25,13 @@ import sys
 import numpy as np
 
 from . import fasta, stats
-from ._lib import (DESC_DTYPE, PFA_ERR_IO, PFA_FILE_DEFERRED, PFA_FILE_NOT_FASTA, PFA_FILE_UNEQUAL,
-                   PFA_FILE_UNSUPPORTED, PFA_FLAG_CDS, PFA_NO_ROW_IDX)
-from .scan import Batch, DeviceBuffer, Plan, finalize_layout, scan_batch
+from ._lib import PFA_ERR_IO, PFA_FILE_NOT_FASTA, PFA_FILE_UNEQUAL, PFA_FILE_UNSUPPORTED
+from .scan import Batch, scan_batch
 
 HEADER_PLAIN = "file,seqlen,pop,N,seg_sites,pi,theta,tajimasD"
 HEADER_CDS = ("file,sites_S,sites_N,pop,N,seg_sites_S,seg_sites_N,pi_S,pi_N,theta_S,theta_N,"
               "tajimasD_S,tajimasD_N,nstops")
 NO_VAR = "0,0,0,NA"
-
-# two pinned ingest buffers (allocated once per process): the loader threads fill one while
-# the other is uploaded and scanned
-BATCH_BYTES = 384 << 20
-FILES_PER_CALL = 8192
-_pinned_cache = [None, None]
-
-
-def _ingest_buffer(slot, min_bytes=0):
-    """Process-wide pinned ingest buffers (hipHostMalloc costs ~60 ms per GB, so they
-    are sized once and reused by every batch)."""
-    want = max(BATCH_BYTES, int(min_bytes))
-    if _pinned_cache[slot] is None or len(_pinned_cache[slot].array) < want:
-        if _pinned_cache[slot] is not None:
-            _pinned_cache[slot].free()
-        _pinned_cache[slot] = fasta.PinnedBuffer(want)
-    return _pinned_cache[slot]
-
 
 # field order of pfa_result / RESULT_DTYPE
 _H, _HS, _HN, _SEG, _BAD, _SEGS, _SEGN, _STOPS, _MISSING = range(9)
@@ -136,6 +117,13 @@ class Sink:
         else:
             sys.stdout.write(block)
 
+    def rows_with_progress(self, block, names, pops):
+        """--out without --silent, a block of rows at once: the same bytes on stdout (one progress
+        piece per row, PolyFastA.py:159,177,186,195) and in the file as row-by-row writing leaves"""
+        sys.stdout.write("".join(f"\r Writting to {self.out}, pop: {p:<10s}, parsing: {n:<15s}" for n, p in zip(names, pops)))
+        sys.stdout.flush()
+        self._write(block[:-1])
+
     def row(self, text, name, pop):
         if self.out:
             if not self.silent:
@@ -171,30 +159,6 @@ def build_parser():
     p.add_argument("--sfs", action="store_true", default=False,
                    help="(polyfasta_amd) append a column `sfs`: the folded site-frequency spectrum, bins 1..N/2 joined by ';'.")
     return p
-
-
-_device_cache = [None]
-
-
-def _device_buffer(nbytes):
-    """One device buffer for the ingest batches of this process (a batch is scanned and its
-    records fetched before the next one is uploaded), grown on demand."""
-    if _device_cache[0] is None or _device_cache[0].nbytes < nbytes:
-        if _device_cache[0] is not None:
-            _device_cache[0].free()
-        _device_cache[0] = DeviceBuffer(max(int(nbytes), 16))
-    return _device_cache[0]
-
-
-def _scan_uploaded(dev, used, descs, row_idx):
-    """Scan every unit of a batch whose bases are already on their way to `dev`."""
-    table = finalize_layout(descs, row_idx, used)
-    plan = Plan(table)
-    try:
-        plan.run(dev)
-        return plan.fetch()          # synchronises the stream: upload, scan and record copy are done
-    finally:
-        plan.close()
 
 
 def _events_for(fidx, path, name, status, names, n_rows, seqlen, args, add_unit):
@@ -241,151 +205,25 @@ def _attach(pending, out, done, want_sfs=False):
             done.append(ev)
 
 
-def process_files(indexed_paths, args, more=None):
-    """Ingest (native multi-threaded packer), scan (one launch per batch) and
-    return the ordered output events of the given (index, path) pairs
-    (PolyFastA.py:104-140).  `more()` (multi-GPU work queue) hands out further pairs
-    whenever the local list runs dry, [] when there are none left."""
+def process_pipe(indexed_paths, args):
+    """--pipe: one alignment from standard input (PolyFastA.py:96-100, 230-236), parsed by the
+    native packer, scanned as one small batch; returns its output events."""
     done = []
-    if args.pipe:
-        for fidx, path in indexed_paths:
-            from ._lib import PFA_ERR_UNSUPPORTED, PfaError
-            try:
-                aln = fasta.read_fasta_stdin(stride_align=128)
-                status = PFA_FILE_NOT_FASTA if aln is None else (0 if aln.same_length else PFA_FILE_UNEQUAL)
-            except PfaError as e:
-                if e.code != PFA_ERR_UNSUPPORTED:
-                    raise
-                aln, status = None, PFA_FILE_UNSUPPORTED
-            batch = Batch(stride_align=128)
-            mid = batch.add_matrix(aln.matrix) if status == 0 else None
-            pending = _events_for(fidx, path, path.split("/")[-1], status, aln.names if aln else None,
-                                  aln.n_rows if aln else 0, int(aln.seq_lens[0]) if status == 0 else 0, args,
-                                  lambda rows: batch.add_unit(mid, rows=None if rows is None else np.asarray(rows, dtype=np.uint32), cds=args.cds))
-            _attach(pending, scan_batch(batch) if batch.n_units else None, done, args.sfs)
-        return done
-
-    from collections import deque
-    from concurrent.futures import ThreadPoolExecutor
-    queue = deque(indexed_paths)
-    want_names = bool(args.pops)
-
-    def refill():
-        if more is not None and not queue:
-            queue.extend(more())
-        return bool(queue)
-
-    def next_chunk(cap):
-        """files whose text adds up to at most ~85 % of a buffer (packed size ~ text size)"""
-        chunk, size = [], 0
-        # (shared work queue: one claim per batch — a rank never hoards what another could scan meanwhile)
-        while (queue or (not chunk and refill())) and len(chunk) < FILES_PER_CALL:
-            try:
-                sz = os.path.getsize(queue[0][1])
-            except OSError:
-                sz = 0
-            if chunk and size + sz > 0.85 * cap:
-                break
-            chunk.append(queue.popleft())
-            size += sz
-        return chunk
-
-    def load(chunk, slot, min_bytes=0):
-        buf = _ingest_buffer(slot, min_bytes)
-        return chunk, buf, fasta.load_files([p for _, p in chunk], buf.array, stride_align=128, want_names=want_names)
-
-    pool = ThreadPoolExecutor(max_workers=1)     # the native loader runs its own thread pool; this thread only overlaps it
-    try:
-        slot = 0
-        first = next_chunk(BATCH_BYTES)
-        fut = pool.submit(load, first, slot) if first else None
-        while fut is not None:
-            chunk, pinned, (info, names, used) = fut.result()
-            status = info["status"]
-            if (status == PFA_ERR_IO).any():
-                path = chunk[int(np.flatnonzero(status == PFA_ERR_IO)[0])][1]
-                open(path, "rb").close()          # raises the OSError the reference would raise (:239)
-                raise OSError(f"cannot read {path}")
-            dev = None
-            if used and (status == 0).any():
-                # the H2D copy starts now and runs under the host work below (next ingest request,
-                # descriptor table, plan); the pinned buffer is not touched again before the fetch
-                dev = _device_buffer(used)
-                dev.upload_async(pinned.array[:used])
-            nxt = next_chunk(BATCH_BYTES)
-            fut = pool.submit(load, nxt, 1 - slot) if nxt else None      # ingest of the next batch overlaps this one's scan
-            deferred = [chunk[k] for k in np.flatnonzero(status == PFA_FILE_DEFERRED)]
-            descs, ridx, pending = [], None, []
-            if not args.pops:
-                # one unit per packed file: build the descriptor table without a Python loop
-                ok = np.flatnonzero(status == 0)
-                descs = np.zeros(len(ok), dtype=DESC_DTYPE)
-                for f in ("base_off", "n_sites", "row_stride"):
-                    descs[f] = info[f][ok]
-                descs["n_rows"] = descs["mat_rows"] = info["n_rows"][ok]
-                descs["row_idx_off"] = PFA_NO_ROW_IDX
-                descs["flags"] = PFA_FLAG_CDS if args.cds else 0
-                unit_of = dict(zip(ok.tolist(), range(len(ok))))
-                for k, fi in enumerate(info.tolist()):
-                    st = fi[0]
-                    if st == PFA_FILE_DEFERRED:
-                        continue
-                    fidx, path = chunk[k]
-                    pending += _events_for(fidx, path, path.split("/")[-1], st, None, fi[1], fi[2], args,
-                                           lambda rows, k=k: unit_of[k])
-            else:
-                # one unit per (file, population): descriptor columns collected as Python lists, the table
-                # built once per batch
-                cols = {f: [] for f in ("base_off", "n_sites", "row_stride", "mat_rows", "n_rows", "row_idx_off")}
-                rl, nri = [], [0]
-                for k, fi in enumerate(info.tolist()):
-                    st = fi[0]
-                    if st == PFA_FILE_DEFERRED:
-                        continue
-                    fidx, path = chunk[k]
-
-                    def add_unit(rows, fi=fi):
-                        cols["base_off"].append(fi[4])
-                        cols["n_sites"].append(fi[2])
-                        cols["row_stride"].append(fi[3])
-                        cols["mat_rows"].append(fi[1])
-                        cols["n_rows"].append(len(rows))
-                        cols["row_idx_off"].append(nri[0])
-                        nri[0] += len(rows)
-                        rl.append(rows)
-                        return len(rl) - 1
-                    pending += _events_for(fidx, path, path.split("/")[-1], st, names[k], fi[1], fi[2], args, add_unit)
-                descs = np.zeros(len(rl), dtype=DESC_DTYPE)
-                for f, v in cols.items():
-                    descs[f] = v
-                descs["flags"] = PFA_FLAG_CDS if args.cds else 0
-                ridx = np.fromiter((r for rows in rl for r in rows), dtype=np.uint32, count=nri[0]) if rl else None
-            if len(descs):
-                out = _scan_uploaded(dev, used, descs, ridx)
-            else:
-                out = None
-                if dev is not None:
-                    from . import _lib
-                    _lib.check(_lib.load().pfa_sync())
-            _attach(pending, out, done, args.sfs)
-            if deferred:
-                if len(deferred) == len(chunk):
-                    # nothing fitted: the first file alone is larger than the buffer.  Let the ingest in
-                    # flight finish, then load that file alone into a buffer grown to its size.
-                    if fut is not None:
-                        queue.extendleft(reversed(fut.result()[0]))
-                    need = (int(info[0]["row_stride"]) << 8) + (1 << 20)
-                    queue.extendleft(reversed(deferred[1:]))
-                    fut = pool.submit(load, deferred[:1], slot, need)
-                    continue
-                queue.extendleft(reversed(deferred))
-                if fut is None:
-                    nxt = next_chunk(BATCH_BYTES)
-                    fut = pool.submit(load, nxt, 1 - slot) if nxt else None
-            slot = 1 - slot
-    finally:
-        pool.shutdown(wait=True)
-    done.sort(key=lambda ev: ev[0])       # stable: deferred files return to their sorted position
+    for fidx, path in indexed_paths:
+        from ._lib import PFA_ERR_UNSUPPORTED, PfaError
+        try:
+            aln = fasta.read_fasta_stdin(stride_align=128)
+            status = PFA_FILE_NOT_FASTA if aln is None else (0 if aln.same_length else PFA_FILE_UNEQUAL)
+        except PfaError as e:
+            if e.code != PFA_ERR_UNSUPPORTED:
+                raise
+            aln, status = None, PFA_FILE_UNSUPPORTED
+        batch = Batch(stride_align=128)
+        mid = batch.add_matrix(aln.matrix) if status == 0 else None
+        pending = _events_for(fidx, path, path.split("/")[-1], status, aln.names if aln else None,
+                              aln.n_rows if aln else 0, int(aln.seq_lens[0]) if status == 0 else 0, args,
+                              lambda rows: batch.add_unit(mid, rows=None if rows is None else np.asarray(rows, dtype=np.uint32), cds=args.cds))
+        _attach(pending, scan_batch(batch) if batch.n_units else None, done, args.sfs)
     return done
 
 
@@ -516,55 +354,256 @@ def emit(events, sink, cds, jc, sfs=False):
     sink.flush()
 
 
-def gather_events(comm, events):
-    """Multi-GPU: the integer records (and, for coding runs, the bins of synonymous-site
-    numerators) travel as fixed-size structs through the communicator's all-gather (RCCL on
-    the GPU box), the small text metadata (names, comment lines, --sfs vectors) as one pickled
-    blob per rank.  Returns the merged, file-ordered event list on rank 0 (None elsewhere)."""
-    from ._lib import PFA_SYN_BINS, RESULT_DTYPE
-    units = [ev for ev in events if ev[1] == "unit"]
-    rec = np.zeros(len(units), dtype=RESULT_DTYPE)
-    if units:
-        rec[:] = np.array([_fields(ev[6]) for ev in units], dtype=RESULT_DTYPE)
-    any_syn = any(ev[7] is not None for ev in units)
-    syn = np.zeros((len(units), PFA_SYN_BINS), dtype=np.uint32)
-    for i, ev in enumerate(units):
-        if ev[7] is not None:
-            syn[i] = ev[7]
-    all_rec = comm.all_gather_records(rec)
-    all_syn = comm.all_gather_records(syn.reshape(-1) if any_syn else syn[:0].reshape(-1))
-    meta = [ev[:6] + (ev[8],) if ev[1] == "unit" else ev for ev in events]      # no numpy payload
-    all_meta = comm.gather_objects(meta, dst=0)
-    if comm.rank != 0:
-        return None
-    merged = []
-    for r in range(comm.world):
-        k = 0
-        syn_r = all_syn[r].reshape(-1, PFA_SYN_BINS) if len(all_syn[r]) else None
-        rec_r = all_rec[r].tolist()
-        for seq, ev in enumerate(all_meta[r]):
-            if ev[1] == "unit":
-                merged.append((ev[0], r, seq, ev[:6] + (rec_r[k], syn_r[k] if syn_r is not None else None, ev[6])))
-                k += 1
+# ---------------------------------------------------------------- row blocks
+# What a run of scanned files turns into, as arrays: one entry per CSV row-to-be (file index, key
+# index, N, alignment length, device record, bins of synonymous-site numerators), plus the rare
+# lines that are not rows ("specials": comment lines and the always-on-stdout "is not FASTA").
+# Nothing per file happens in Python while a block is regular.
+META_DTYPE = np.dtype([("fidx", "<u4"), ("key", "<u4"), ("n_rows", "<u4"), ("n_sites", "<u4")])
+
+
+class RowBlock:
+    def __init__(self, meta, rec, syn=None, sfs=None, specials=None):
+        self.meta, self.rec, self.syn = meta, rec, syn
+        self.sfs = sfs                    # per unit: list of bins, or None (--sfs only)
+        self.specials = specials or []    # (fidx, sub, kind, text); sub orders the lines of one file
+
+    @staticmethod
+    def concat(blocks, coding):
+        from ._lib import PFA_SYN_BINS, RESULT_DTYPE
+        blocks = [b for b in blocks if b is not None]
+        meta = np.concatenate([b.meta for b in blocks]) if blocks else np.zeros(0, dtype=META_DTYPE)
+        rec = np.concatenate([b.rec for b in blocks]) if blocks else np.zeros(0, dtype=RESULT_DTYPE)
+        syn = None
+        if coding:
+            syn = (np.concatenate([b.syn if b.syn is not None else np.zeros((len(b.meta), PFA_SYN_BINS), dtype=np.uint32) for b in blocks])
+                   if blocks else np.zeros((0, PFA_SYN_BINS), dtype=np.uint32))
+        sfs = None
+        if any(b.sfs is not None for b in blocks):
+            sfs = [x for b in blocks for x in (b.sfs if b.sfs is not None else [None] * len(b.meta))]
+        return RowBlock(meta, rec, syn, sfs, [x for b in blocks for x in b.specials])
+
+    def sorted(self):
+        """file order, then population order as typed (PolyFastA.py:104, :124)"""
+        from ._lib import PFA_NO_KEY
+        sub = np.where(self.meta["key"] == PFA_NO_KEY, 0, self.meta["key"]).astype(np.int64)
+        order = np.lexsort((sub, self.meta["fidx"]))
+        if (order == np.arange(len(order))).all():
+            return self
+        return RowBlock(self.meta[order], self.rec[order], None if self.syn is None else self.syn[order],
+                        None if self.sfs is None else [self.sfs[i] for i in order.tolist()], self.specials)
+
+    def to_bytes(self):
+        import pickle
+        return pickle.dumps((self.meta.tobytes(), self.rec.tobytes(), None if self.syn is None else self.syn.tobytes(),
+                             self.sfs, self.specials), protocol=pickle.HIGHEST_PROTOCOL)
+
+    @staticmethod
+    def from_bytes(blob):
+        import pickle
+        from ._lib import PFA_SYN_BINS, RESULT_DTYPE
+        meta, rec, syn, sfs, specials = pickle.loads(blob)
+        return RowBlock(np.frombuffer(meta, dtype=META_DTYPE).copy(), np.frombuffer(rec, dtype=RESULT_DTYPE).copy(),
+                        None if syn is None else np.frombuffer(syn, dtype=np.uint32).reshape(-1, PFA_SYN_BINS).copy(), sfs, specials)
+
+
+def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
+    """The rows and special lines of one ingest batch (PolyFastA.py:107-140).  Irregular files —
+    not FASTA, unequal lengths, non-ASCII sequence bytes, a coding length that is not a multiple of
+    3, a population key without a match — are the only ones visited one by one."""
+    from ._lib import PFA_NO_KEY
+    nu = b.n_units
+    meta = np.zeros(nu, dtype=META_DTYPE)
+    meta["fidx"] = b.file_idx[b.unit_file]
+    meta["key"] = b.unit_key
+    meta["n_rows"] = b.unit_rows
+    meta["n_sites"] = b.n_sites[b.unit_file]
+    specials = []
+    keep = None
+    bad = b.bad != 0 if b.bad is not None and len(b.bad) else np.zeros(b.n_files, dtype=bool)
+    if not b.regular or bad.any():
+        st = b.status
+        if (st == PFA_ERR_IO).any():
+            path = paths[int(b.file_idx[int(np.flatnonzero(st == PFA_ERR_IO)[0])])]
+            open(path, "rb").close()          # raises the OSError the reference would raise (PolyFastA.py:239)
+            raise OSError(f"cannot read {path}")
+        odd = (st != 0) | bad
+        if args.cds:
+            odd |= (st == 0) & (b.n_sites % 3 != 0)
+        if b.key_rows is not None:
+            odd |= (st == 0) & (b.key_rows == 0).any(axis=1)
+        for k in np.flatnonzero(odd).tolist():
+            fidx = int(b.file_idx[k])
+            path = paths[fidx]
+            name = path.split("/")[-1]
+            if st[k] == PFA_FILE_NOT_FASTA:
+                specials.append((fidx, 0, "stdout", f"# file {path} is not FASTA!"))                        # :247 (always stdout)
+            elif st[k] == PFA_FILE_UNEQUAL:
+                specials.append((fidx, 0, "comment", f"# Sequences do not have the same length: {name}"))   # :135-140
+            elif bad[k]:    # this file only: the rest of the batch is scanned (DESIGN.md, deviations)
+                specials.append((fidx, 0, "comment", f"# Sequences hold non-ASCII characters (not supported, one byte per base): {name}"))
             else:
-                merged.append((ev[0], r, seq, ev))
-    merged.sort(key=lambda t: (t[0], t[1], t[2]))
-    return [t[3] for t in merged]
+                if args.cds and int(b.n_sites[k]) % 3 != 0:                                                  # :114-119
+                    specials.append((fidx, 0, "comment", f"# CDS sequence length is not a multiple of 3: {name}"))
+                if b.key_rows is not None:
+                    for j in np.flatnonzero(b.key_rows[k] == 0).tolist():                                    # :126-131
+                        specials.append((fidx, 1 + j, "comment", f"# Pop {keys[j]} string was not found in fasta headers."))
+        if bad.any():
+            keep = ~bad[b.unit_file]
+    sfs = None
+    if args.sfs and nu:
+        off = b.sfs_offsets().tolist()
+        nbad = res["sfs_bad"].tolist()
+        nr = b.unit_rows.tolist()
+        sfs = [None if nbad[i] else sfs_flat[off[i]:off[i] + nr[i] // 2].tolist() for i in range(nu)]
+    if keep is not None:
+        meta, res = meta[keep], res[keep]
+        syn = None if syn is None else syn[keep]
+        sfs = None if sfs is None else [x for x, k in zip(sfs, keep.tolist()) if k]
+    return RowBlock(meta, res, syn, sfs, specials)
 
 
-def _file_sizes(paths):
-    sizes = []
-    for p in paths:
-        try:
-            sizes.append(os.path.getsize(p))
-        except OSError:
-            sizes.append(0)
-    return sizes
+def block_events(blk, paths, keys):
+    """The block as the ordered event list `emit()` takes (the per-row path: --sfs, special
+    lines, rows the native formatter hands back)."""
+    from ._lib import PFA_NO_KEY
+    items = []
+    m = blk.meta.tolist()
+    rec = blk.rec.tolist()
+    for i, (fidx, key, n_rows, n_sites) in enumerate(m):
+        pop = "NA" if key == PFA_NO_KEY else keys[key]
+        items.append((fidx, 0 if key == PFA_NO_KEY else 1 + key, 1,
+                      (fidx, "unit", paths[fidx].split("/")[-1], pop, n_rows, n_sites, rec[i],
+                       None if blk.syn is None else blk.syn[i], None if blk.sfs is None else blk.sfs[i])))
+    for fidx, sub, kind, text in blk.specials:
+        items.append((fidx, sub, 0, (fidx, kind, text)))
+    items.sort(key=lambda t: t[:3])
+    return [t[3] for t in items]
+
+
+def format_block_native(blk, table, coding, jc):
+    """Every row of a block in one call into the library (csrc/pfa_format.cpp:
+    pfa_format_rows_indexed); names and population keys are looked up natively in `table`
+    (ingest.NameTable).  None when some row needs the Python path (the reference would raise there)."""
+    import ctypes
+    from . import _lib
+    n = len(blk.meta)
+    m = blk.meta
+    fidx, key, nrows, nsites = (np.ascontiguousarray(m[f]) for f in ("fidx", "key", "n_rows", "n_sites"))
+    a1, e1, e2 = _sample_size_constants(nrows)
+    rec = np.ascontiguousarray(blk.rec)
+    syn = np.ascontiguousarray(blk.syn) if coding else None
+    out = np.empty((448 if coding else 192) * n + 512 + table.row_bytes(fidx), dtype=np.uint8)
+    bad = ctypes.c_int64(-1)
+    got = _lib.load().pfa_format_rows_indexed(_lib.ptr(table.names_blob), _lib.ptr(table.names_off), _lib.ptr(table.keys_blob),
+                                              _lib.ptr(table.keys_off), n, _lib.ptr(fidx), _lib.ptr(key), _lib.ptr(nrows),
+                                              _lib.ptr(nsites), _lib.ptr(rec), _lib.ptr(syn), _lib.ptr(a1), _lib.ptr(e1), _lib.ptr(e2),
+                                              int(bool(jc)), int(bool(coding)), _lib.ptr(out), len(out), ctypes.byref(bad))
+    if got < 0:
+        if bad.value >= 0:
+            return None
+        _lib.check(got)
+    return out[:got].tobytes().decode("utf-8", "surrogateescape")
+
+
+def emit_block(blk, sink, args, table, paths, keys):
+    """Write a block: natively formatted in one piece while it holds nothing but rows, else event by event."""
+    from ._lib import PFA_NO_KEY
+    n = len(blk.meta)
+    if n == 0 and not blk.specials:
+        return
+    if n and not blk.specials and not args.sfs:
+        text = format_block_native(blk, table, args.cds, args.jc)
+        if text is not None:
+            if sink.bulk_ok():
+                sink.rows(text)
+            else:    # --out without --silent: the reference's progress chatter, one piece per row, then the rows
+                names = [paths[i].split("/")[-1] for i in blk.meta["fidx"].tolist()]
+                pops = ["NA" if k == PFA_NO_KEY else keys[k] for k in blk.meta["key"].tolist()]
+                sink.rows_with_progress(text, names, pops)
+            return
+    emit(block_events(blk, paths, keys), sink, args.cds, args.jc, args.sfs)
+
+
+last_stats = {}     # what the last run_files() measured (bench.py `end_to_end`: the stage breakdown)
+
+
+def run_files(paths, args, sink, rank, world, comm, wq, keys):
+    """The file loop (PolyFastA.py:104-140) on the streaming ingest.  One rank: rows leave batch by
+    batch while later files are still being read.  Several ranks: every rank drains the shared
+    queue, the blocks travel to rank 0 once (`comm.gather_bytes`), rank 0 orders and writes them."""
+    import time
+    from . import ingest
+    trace = [] if os.environ.get("PFA_TRACE") else None      # per-batch timeline on stderr (tools/e2e_modes_probe.py)
+    t00 = time.perf_counter()
+    ing = ingest.Ingest(paths, keys=keys, cds=args.cds)
+    t_open = time.perf_counter() - t00
+    if trace is not None:
+        trace.append(("open", time.perf_counter() - t00, len(paths)))
+    try:
+        drained = [wq is None]
+        if wq is None:
+            ing.feed(None, last=True)
+
+        def top_up():
+            # keep two claims' worth of files in the loader's hands; one claim = one grain of the queue
+            while not drained[0] and ing.backlog() < 2 * wq.grain:
+                got = wq.claim()
+                if not got:
+                    drained[0] = True
+                ing.feed(got, last=not got)
+        kept = []
+        t_fetch = t_emit = 0.0
+        while True:
+            top_up()
+            t0 = time.perf_counter()
+            b = ing.next()
+            if b is None:
+                break
+            t1 = time.perf_counter()
+            res, syn, sfs_flat = b.fetch(args.cds, want_sfs=args.sfs)
+            t2 = time.perf_counter()
+            blk = block_from_batch(b, res, syn, sfs_flat, args, paths, keys)
+            if world == 1:
+                emit_block(blk, sink, args, ing.table, paths, keys)
+            else:
+                kept.append(blk)
+            t3 = time.perf_counter()
+            t_fetch += t2 - t1
+            t_emit += t3 - t2
+            if trace is not None:
+                trace.append(("batch", t0 - t00, b.n_files, t1 - t0, t2 - t1, t3 - t2))
+        if world > 1:
+            mine = RowBlock.concat(kept, args.cds)
+            parts = comm.gather_bytes(mine.to_bytes(), dst=0)
+            if rank == 0:
+                allb = RowBlock.concat([RowBlock.from_bytes(p) for p in parts], args.cds).sorted()
+                emit_block(allb, sink, args, ing.table, paths, keys)
+        if trace is not None:
+            trace.append(("loop_end", time.perf_counter() - t00))
+        t4 = time.perf_counter()
+        sink.flush()
+        st = ing.stats()
+        st.update(files=len(paths), open_s=t_open, wall_s=time.perf_counter() - t00, fetch_wait_s=t_fetch, rows_s=t_emit, flush_s=time.perf_counter() - t4)
+        last_stats.clear()
+        last_stats.update(st)
+        if trace is not None:
+            print("PFA_TRACE", {k: (round(v, 5) if isinstance(v, float) else v) for k, v in st.items()}, "total", round(time.perf_counter() - t00, 5), file=sys.stderr)
+            for t in trace:
+                print("PFA_TRACE", t[0], *(round(x, 5) if isinstance(x, float) else x for x in t[1:]), file=sys.stderr)
+        return st
+    finally:
+        t9 = time.perf_counter()
+        ing.close()
+        if trace is not None:
+            print("PFA_TRACE close", round(time.perf_counter() - t9, 5), file=sys.stderr)
 
 
 def main(argv=None, comm=None):
     """`comm`: a dist.Comm to use instead of RCCL (tests); with WORLD_SIZE > 1 and no `comm`
     the ranks talk through dist.RcclComm."""
+    import time
+    t_main = time.perf_counter()
     parser = build_parser()
     args = parser.parse_args(argv)
 
@@ -592,6 +631,13 @@ def main(argv=None, comm=None):
     elif args.gpus > 1 and world != args.gpus:
         print(f"polyfasta_amd: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         return 2
+    if comm is None and world > 1 and not dist.single_node(world):
+        print("polyfasta_amd: the ranks share a work queue and a rendezvous file of ONE node; "
+              f"LOCAL_WORLD_SIZE={os.environ.get('LOCAL_WORLD_SIZE')} != WORLD_SIZE={world} (run one job per node)", file=sys.stderr)
+        return 2
+    # the CPUs next to this rank's GPU, before the first GPU call: pinned buffers and loader threads then
+    # sit on the socket the card hangs off (H2D from the other socket ran 33 instead of 54 GB/s here)
+    dist.bind_to_gpu_node(dist.env_world()[1], int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     try:                                   # the scan runs on the GPU or not at all: say so before any output
         _lib.init()                        # GPU LOCAL_RANK
         if comm is None and (world > 1 or os.environ.get("PFA_FORCE_DIST")):   # PFA_FORCE_DIST: one-rank RCCL rehearsal
@@ -604,25 +650,28 @@ def main(argv=None, comm=None):
     if rank == 0:
         sink.header(args.cds, args.sfs)                                            # :102-103
     paths = sorted(args.file)                                                      # :104
+    keys = args.pops.split(",") if args.pops else []                               # :123
     if args.pipe:
-        mine = [(0, paths[0])] if rank == 0 and paths else []
-    elif world > 1:
-        mine = []          # everything comes out of the work queue the ranks share
+        events = process_pipe([(0, paths[0])] if rank == 0 and paths else [], args)
+        if comm is not None:
+            comm.barrier()
+        if rank == 0:
+            emit(events, sink, args.cds, args.jc, args.sfs)
     else:
-        mine = list(enumerate(paths))
-    wq = None
-    if world > 1 and not args.pipe:
-        wq = dist.WorkQueue(_file_sizes(paths), world)
-    events = process_files(mine, args, more=(lambda: [(i, paths[i]) for i in wq.claim()]) if wq else None)
-    if comm is not None:
-        events = gather_events(comm, events)
-        comm.barrier()
-    if wq is not None:
-        wq.close(unlink=rank == 0)       # every rank is past its last claim: the barrier above
-    if rank == 0:
-        emit(events, sink, args.cds, args.jc, args.sfs)
-        if len(args.out) != 0 and not args.silent:                                 # :141-142
-            print("")
+        wq = dist.WorkQueue(len(paths), world) if world > 1 else None            # the ranks of the node share the file loop
+        if os.environ.get("PFA_TRACE"):
+            print("PFA_TRACE before_run_files", round(time.perf_counter() - t_main, 5), file=sys.stderr)
+        try:
+            run_files(paths, args, sink, rank, world, comm, wq, keys)
+            if os.environ.get("PFA_TRACE"):
+                print("PFA_TRACE after_run_files", round(time.perf_counter() - t_main, 5), file=sys.stderr)
+            if comm is not None:
+                comm.barrier()
+        finally:
+            if wq is not None:
+                wq.close(unlink=rank == 0)       # every rank is past its last claim: the barrier above
+    if rank == 0 and len(args.out) != 0 and not args.silent:                       # :141-142
+        print("")
     if comm is not None:
         comm.close()
     return 0

@@ -23,6 +23,10 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -65,6 +69,10 @@ int bind_rccl(Rccl& r) {
   PFA_SYM(CommDestroy, "ncclCommDestroy");
   PFA_SYM(AllGather, "ncclAllGather");
   PFA_SYM(AllReduce, "ncclAllReduce");
+  PFA_SYM(Send, "ncclSend");
+  PFA_SYM(Recv, "ncclRecv");
+  PFA_SYM(GroupStart, "ncclGroupStart");
+  PFA_SYM(GroupEnd, "ncclGroupEnd");
   PFA_SYM(GetErrorString, "ncclGetErrorString");
 #undef PFA_SYM
   return PFA_OK;
@@ -180,6 +188,43 @@ int pfa_comm_all_gather(const void* send_host, void* recv_host, size_t bytes_per
   PFA_HIP(hipMemcpyAsync(d_send, send_host, bytes_per_rank, hipMemcpyHostToDevice, st));
   PFA_NCCL(g_comm.api.AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, g_comm.comm, st));
   PFA_HIP(hipMemcpyAsync(recv_host, d_recv, w * bytes_per_rank, hipMemcpyDeviceToHost, st));
+  PFA_HIP(hipStreamSynchronize(st));
+  return PFA_OK;
+}
+
+int pfa_comm_gatherv(const void* send_host, uint64_t send_bytes, void* recv_host, const uint64_t* counts, int root) {
+  PFA_NEED_COMM();
+  const int w = g_comm.world, me = g_comm.rank;
+  if (!counts || root < 0 || root >= w || (send_bytes && !send_host)) { pfa::set_error("pfa_comm_gatherv: bad argument"); return PFA_ERR_ARG; }
+  if (counts[me] != send_bytes) { pfa::set_error("pfa_comm_gatherv: counts[%d] = %llu but %llu bytes are sent", me, (unsigned long long)counts[me], (unsigned long long)send_bytes); return PFA_ERR_ARG; }
+  uint64_t total = 0;
+  for (int r = 0; r < w; ++r) total += counts[r];
+  if (me == root && total && !recv_host) { pfa::set_error("pfa_comm_gatherv: recv_host is NULL on the root"); return PFA_ERR_ARG; }
+  // staging: [ my bytes | (root) everybody's bytes, rank after rank ], both on 256-byte boundaries
+  const size_t send_span = ((size_t)send_bytes + 255u) & ~size_t(255);
+  int rc = need_stage(send_span + (me == root ? (size_t)total : 0) + 256u);
+  if (rc != PFA_OK) return rc;
+  hipStream_t st = pfa::ctx().stream;
+  uint8_t* const d_send = g_comm.d_stage;
+  uint8_t* const d_recv = g_comm.d_stage + send_span;
+  if (send_bytes) PFA_HIP(hipMemcpyAsync(d_send, send_host, (size_t)send_bytes, hipMemcpyHostToDevice, st));
+  PFA_NCCL(g_comm.api.GroupStart());
+  if (me == root) {
+    uint64_t off = 0;
+    for (int r = 0; r < w; ++r) {
+      if (counts[r] && r != me) PFA_NCCL(g_comm.api.Recv(d_recv + off, (size_t)counts[r], ncclUint8, r, g_comm.comm, st));
+      off += counts[r];
+    }
+  } else if (send_bytes) {
+    PFA_NCCL(g_comm.api.Send(d_send, (size_t)send_bytes, ncclUint8, root, g_comm.comm, st));
+  }
+  PFA_NCCL(g_comm.api.GroupEnd());
+  if (me == root) {
+    uint64_t off = 0;
+    for (int r = 0; r < me; ++r) off += counts[r];
+    if (send_bytes) PFA_HIP(hipMemcpyAsync(d_recv + off, d_send, (size_t)send_bytes, hipMemcpyDeviceToDevice, st));   // the root's own part
+    if (total) PFA_HIP(hipMemcpyAsync(recv_host, d_recv, (size_t)total, hipMemcpyDeviceToHost, st));
+  }
   PFA_HIP(hipStreamSynchronize(st));
   return PFA_OK;
 }

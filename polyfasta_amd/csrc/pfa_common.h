@@ -19,6 +19,7 @@ struct Context {
 
 Context& ctx();
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+void ingest_release_cache();   // pfa_ingest.hip: pinned slots and device buffers kept between ingests
 
 }  // namespace pfa
 

@@ -32,10 +32,7 @@
 #include <vector>
 
 #include "../../include/pfa.h"
-
-namespace pfa {
-void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
-}
+#include "pfa_host.h"
 static std::string pfa_last_error_local() { return std::string(pfa_last_error()); }
 
 namespace {
@@ -76,6 +73,94 @@ inline uint64_t rstrip_end(const uint8_t* t, uint64_t b, uint64_t e) {
 }
 
 }  // namespace
+
+// ---- single-pass index for the streaming ingest (pfa_ingest.hip) ---------------
+// One pass over the text of a file that sits in the pinned staging ring: the records, their
+// names, and for every record ONE contiguous run of raw sequence bytes.  Records written on
+// several lines are compacted in place (the stripped lines are moved together: the destination
+// never passes the source); single-line records — what the reference's examples and most
+// pipelines write — are not touched at all.  Upper-casing and the byte >= 0x80 test are left to
+// the card (repack_kernel), which reads every byte anyway.  Same record rules as
+// fasta_index_impl above (PolyFastA.py:227-250).
+namespace pfa {
+
+int64_t index_compact(uint8_t* text, uint64_t n_text, std::vector<pfa_fasta_row>& rows, IndexScratch& sc) {
+  rows.clear();
+  sc.by_name.clear();
+  sc.spans.clear();
+  if (!text && n_text) { set_error("index_compact: text is NULL"); return PFA_ERR_ARG; }
+  // a file without any '\r' (the usual case) needs no second look at its lines
+  const bool has_cr = n_text && memchr(text, '\r', n_text) != nullptr;
+  bool have_head = false, head_named = false, multi = false;
+  size_t cur = 0;
+  uint64_t pos = 0;
+  while (pos < n_text) {
+    uint64_t e, nx;
+    if (!has_cr) {
+      const uint8_t* nl = static_cast<const uint8_t*>(memchr(text + pos, '\n', n_text - pos));
+      e = nl ? uint64_t(nl - text) : n_text;
+      nx = nl ? e + 1 : n_text;
+    } else {
+      const Line ln = next_line(text, n_text, pos);
+      e = ln.end;
+      nx = ln.next;
+    }
+    if (text[pos] == '>') {
+      if (have_head) sc.spans[cur].end = pos;
+      const uint64_t nb = pos + 1, ne = rstrip_end(text, nb > e ? e : nb, e);
+      std::string_view name(reinterpret_cast<const char*>(text + nb), ne > nb ? ne - nb : 0);
+      auto it = sc.by_name.find(name);
+      if (it == sc.by_name.end()) {
+        rows.push_back(pfa_fasta_row{nb, (uint32_t)name.size(), 0u, nx});
+        sc.spans.push_back(IndexScratch::Span{nx, nx, 0u});
+        cur = rows.size() - 1;
+        sc.by_name.emplace(name, (uint32_t)cur);
+      } else {   // a repeated name starts over but keeps its first position (dict)
+        cur = it->second;
+        rows[cur].seq_len = 0;
+        rows[cur].seq_off = nx;
+        sc.spans[cur] = IndexScratch::Span{nx, nx, 0u};
+      }
+      have_head = true;
+      head_named = !name.empty();
+    } else if (head_named) {
+      const uint64_t e2 = rstrip_end(text, pos, e);
+      const uint64_t add = e2 - pos;
+      if (add) {
+        if ((uint64_t)rows[cur].seq_len + add > 0xFFFFFFFFull) { set_error("sequence longer than 2^32-1"); return PFA_ERR_FORMAT; }
+        if (sc.spans[cur].n_lines == 0) rows[cur].seq_off = pos;
+        else multi = true;
+        rows[cur].seq_len += (uint32_t)add;
+        sc.spans[cur].n_lines += 1;
+      }
+    }
+    pos = nx;
+  }
+  if (have_head) sc.spans[cur].end = n_text;
+  if (!have_head || !head_named) {
+    set_error("not FASTA: no header line, or the last header is empty");
+    return PFA_ERR_FORMAT;
+  }
+  if (multi) {
+    for (size_t r = 0; r < rows.size(); ++r) {
+      if (sc.spans[r].n_lines < 2) continue;
+      uint64_t w = rows[r].seq_off, p = rows[r].seq_off;
+      const uint64_t end = sc.spans[r].end;
+      while (p < end) {
+        const Line ln = next_line(text, end, p);
+        const uint64_t e2 = rstrip_end(text, ln.begin, ln.end);
+        if (e2 > ln.begin) {
+          if (w != ln.begin) memmove(text + w, text + ln.begin, e2 - ln.begin);
+          w += e2 - ln.begin;
+        }
+        p = ln.next;
+      }
+    }
+  }
+  return (int64_t)rows.size();
+}
+
+}  // namespace pfa
 
 extern "C" {
 
@@ -143,6 +228,25 @@ int64_t pfa_fasta_index(const uint8_t* text, uint64_t n_text, pfa_fasta_rec* rec
     return PFA_ERR_NOMEM;
   } catch (...) {
     pfa::set_error("pfa_fasta_index: unexpected exception");
+    return PFA_ERR_ARG;
+  }
+}
+
+int64_t pfa_fasta_index_compact(uint8_t* text, uint64_t n_text, pfa_fasta_row* rows, uint64_t cap) {
+  try {
+    std::vector<pfa_fasta_row> v;
+    pfa::IndexScratch sc;
+    const int64_t n = pfa::index_compact(text, n_text, v, sc);
+    if (n < 0) return n;
+    if ((uint64_t)n > cap) { pfa::set_error("pfa_fasta_index_compact: %lld records, capacity %llu", (long long)n, (unsigned long long)cap); return PFA_ERR_ARG; }
+    if (n && !rows) { pfa::set_error("pfa_fasta_index_compact: rows is NULL"); return PFA_ERR_ARG; }
+    if (n) memcpy(rows, v.data(), (size_t)n * sizeof(pfa_fasta_row));
+    return n;
+  } catch (const std::bad_alloc&) {
+    pfa::set_error("pfa_fasta_index_compact: out of host memory");
+    return PFA_ERR_NOMEM;
+  } catch (...) {
+    pfa::set_error("pfa_fasta_index_compact: unexpected exception");
     return PFA_ERR_ARG;
   }
 }

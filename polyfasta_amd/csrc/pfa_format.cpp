@@ -222,4 +222,89 @@ int64_t pfa_format_cds_rows(const char* name_blob, const uint64_t* name_off, con
   return (int64_t)w;
 }
 
+int64_t pfa_format_rows_indexed(const char* names_blob, const uint64_t* names_off, const char* keys_blob, const uint64_t* keys_off,
+                                uint32_t n, const uint32_t* file_idx, const uint32_t* key, const uint32_t* n_rows, const uint32_t* n_sites,
+                                const pfa_result* res, const uint32_t* syn_num, const double* a1, const double* e1, const double* e2,
+                                int jc, int coding, char* out, uint64_t cap, int64_t* bad_row) {
+  if (bad_row) *bad_row = -1;
+  if (n && (!names_blob || !names_off || !file_idx || !key || !n_rows || !n_sites || !res || !a1 || !e1 || !e2 || !out || (coding && !syn_num))) {
+    pfa::set_error("pfa_format_rows_indexed: NULL argument");
+    return PFA_ERR_ARG;
+  }
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint64_t nb = names_off[file_idx[i]], nlen = names_off[file_idx[i] + 1] - nb;
+    const char* pop = "NA";
+    uint64_t plen = 2;
+    if (key[i] != PFA_NO_KEY) {
+      if (!keys_blob || !keys_off) { pfa::set_error("pfa_format_rows_indexed: row %u names a key but there are none", i); return PFA_ERR_ARG; }
+      pop = keys_blob + keys_off[key[i]];
+      plen = keys_off[key[i] + 1] - keys_off[key[i]];
+    }
+    if (w + nlen + plen + 400u > cap) { pfa::set_error("pfa_format_rows_indexed: output capacity %llu too small", (unsigned long long)cap); return PFA_ERR_ARG; }
+    memcpy(out + w, names_blob + nb, nlen);
+    w += nlen;
+    out[w++] = ',';
+    if (!coding) {                                          // file,seqlen,pop,N,S,pi,theta,D  (PolyFastA.py:198)
+      w += (uint64_t)pfa::put_u64(n_sites[i], out + w);
+      out[w++] = ',';
+      memcpy(out + w, pop, plen);
+      w += plen;
+      out[w++] = ',';
+      w += (uint64_t)pfa::put_u64(n_rows[i], out + w);
+      out[w++] = ',';
+      const int k = put_polymorphism(res[i].seg_sites, res[i].H, n_rows[i], (double)n_sites[i], a1[i], e1[i], e2[i], jc, out + w);
+      if (k < 0) {
+        if (bad_row) *bad_row = i;
+        pfa::set_error("pfa_format_rows_indexed: row %u has no finite result", i);
+        return PFA_ERR_ARG;
+      }
+      w += (uint64_t)k;
+      out[w++] = '\n';
+      continue;
+    }
+    // file,sites_S,sites_N,pop,N,... (PolyFastA.py:151-180; the same arithmetic as pfa_format_cds_rows)
+    double ssites = 0.0;
+    const uint32_t* bins = syn_num + (uint64_t)i * PFA_SYN_BINS;
+    for (uint32_t k = 1; k < PFA_SYN_BINS; ++k)
+      if (bins[k]) ssites += (double)bins[k] / (3.0 * (double)k);
+    const double nsites = (double)((long long)n_sites[i] - 3ll * (long long)res[i].missing_cols) - ssites;
+    w += pfa::repr_double(py_round2(ssites), out + w);
+    out[w++] = ',';
+    w += pfa::repr_double(py_round2(nsites), out + w);
+    out[w++] = ',';
+    memcpy(out + w, pop, plen);
+    w += plen;
+    out[w++] = ',';
+    w += (uint64_t)pfa::put_u64(n_rows[i], out + w);
+    out[w++] = ',';
+    if (res[i].seg_sites == 0) {                           // PolyFastA.py:160-162
+      memcpy(out + w, "0,0,0,NA,0,0,0,NA,0\n", 20);
+      w += 20;
+      continue;
+    }
+    char ps[128], pn[128];
+    const int ks = put_polymorphism(res[i].seg_S, res[i].H_S, n_rows[i], ssites, a1[i], e1[i], e2[i], jc, ps);
+    const int kn = put_polymorphism(res[i].seg_N, res[i].H_N, n_rows[i], nsites, a1[i], e1[i], e2[i], jc, pn);
+    if (ks < 0 || kn < 0) {
+      if (bad_row) *bad_row = i;
+      pfa::set_error("pfa_format_rows_indexed: row %u has no finite result", i);
+      return PFA_ERR_ARG;
+    }
+    ps[ks] = pn[kn] = ',';
+    const char *a = ps, *b = pn;
+    for (int f = 0; f < 4; ++f) {
+      while (*a != ',') out[w++] = *a++;
+      ++a;
+      out[w++] = ',';
+      while (*b != ',') out[w++] = *b++;
+      ++b;
+      out[w++] = ',';
+    }
+    w += (uint64_t)pfa::put_u64(res[i].nstops, out + w);
+    out[w++] = '\n';
+  }
+  return (int64_t)w;
+}
+
 }  // extern "C"

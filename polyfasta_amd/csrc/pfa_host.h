@@ -1,0 +1,28 @@
+// pfa_host.h — host-side helpers shared by the host translation units of libpfa_hip.so
+// (pfa_fasta.cpp, pfa_ingest.hip); no HIP types.
+#pragma once
+#include <stdint.h>
+
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/pfa.h"
+
+namespace pfa {
+
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+// per-thread scratch of index_compact(), reused from file to file
+struct IndexScratch {
+  struct Span { uint64_t first_line, end; uint32_t n_lines; };
+  std::unordered_map<std::string_view, uint32_t> by_name;
+  std::vector<Span> spans;
+};
+
+// The records of one FASTA text (readfasta's rules, PolyFastA.py:227-250) in one pass; records
+// written on several lines are compacted in place so that every record's sequence is one run
+// of raw bytes.  Returns the record count, PFA_ERR_FORMAT for "not FASTA".
+int64_t index_compact(uint8_t* text, uint64_t n_text, std::vector<pfa_fasta_row>& rows, IndexScratch& sc);
+
+}  // namespace pfa

@@ -1,0 +1,924 @@
+// pfa_ingest.hip — streaming ingest of libpfa_hip.so: FASTA files -> device-resident matrices ->
+// launched scan plans (include/pfa.h: pfa_ingest_*).  The feeder of the reference's file loop
+// (PolyFastA.py:104-140; readfasta :227-250; population split :122-134).
+//
+// What limits files -> CSV is the PCIe link (57 GB/s measured on this pool), provided the host
+// touches every byte once and the card never waits for a whole batch:
+//   loader threads  claim the files in feed order, read() each one ONCE straight into a ring of
+//                   pinned slots (no temporary buffer), index it in place (index_compact: one
+//                   memchr pass; nothing is copied for single-line records) and match the --pops
+//                   keys against its record names.  16 threads read 110 GB/s from tmpfs; more
+//                   threads only fight over the memory controllers (tools/ubench/ingest_probe.hip).
+//   uploader thread copies a slot to the card as soon as its files have landed, on its own stream,
+//                   two copies in flight at most: the link never idles while there is text.
+//   pfa_ingest_next (the caller's thread) takes whatever has been uploaded since its last call,
+//                   lets the card turn the raw text into row-major, stride-aligned, upper-case
+//                   matrices (repack_kernel below: 1 MB of HBM traffic per 500 KB alignment,
+//                   nothing at 6 TB/s), and creates and launches the scan plan of those files.
+// The rows of a record reach the card as (offset, length) pairs; upper-casing and the test for
+// bytes >= 0x80 (outside the one-byte-per-base contract) happen in repack_kernel, which reads
+// every byte anyway.  Nothing here scans on the CPU.
+#include <fcntl.h>
+#include <sched.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "pfa_common.h"
+#include "pfa_host.h"
+
+namespace pfa {
+
+// one record's sequence run: `len` raw bytes at text + src -> packed + dst, upper-cased, the rest
+// of the row (up to its stride) zeroed
+struct Seg {
+  unsigned long long src;
+  unsigned long long dst;
+  uint32_t len;
+  uint32_t file;   // index into the batch's `bad` words
+};
+
+__device__ inline uint32_t swar_upper(uint32_t w) {
+  const uint32_t h = w & 0x7F7F7F7Fu;
+  const uint32_t ge_a = h + 0x1F1F1F1Fu;   // bit 7 of a byte: its low seven bits >= 'a'
+  const uint32_t gt_z = h + 0x05050505u;   // ... > 'z'
+  const uint32_t lower = ge_a & ~gt_z & ~w & 0x80808080u;
+  return w ^ (lower >> 2);
+}
+
+// One workgroup per record.  The source run starts at any byte: every thread reads the five
+// aligned words that cover its 16 output bytes and shifts them into place (v_alignbyte); the
+// destination rows are 16-byte aligned by construction (matrices on 256 bytes, strides multiples
+// of 16).  `bad` lives in pinned host memory (written only when a byte >= 0x80 turns up).
+__global__ void __launch_bounds__(256) repack_kernel(const uint8_t* __restrict__ text, const Seg* __restrict__ segs, uint32_t n_segs,
+                                                     uint8_t* __restrict__ packed, uint32_t stride_align, uint32_t* bad) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  struct __attribute__((packed, aligned(4))) V4 { u32x4 v; };
+  for (uint32_t s = blockIdx.x; s < n_segs; s += gridDim.x) {
+    const Seg g = segs[s];
+    const uint8_t* const src = text + g.src;
+    uint8_t* const dst = packed + g.dst;
+    const uint32_t len = g.len;
+    uint32_t stride = (len + stride_align - 1u) & ~(stride_align - 1u);
+    if (stride < 16u) stride = 16u;
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
+    uint32_t seen = 0u;
+    for (uint32_t i = threadIdx.x * 16u; i < stride; i += 256u * 16u) {
+      u32x4 o = {0u, 0u, 0u, 0u};
+      if (i < len) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(src + i) & ~uintptr_t(3));
+        const u32x4 a = reinterpret_cast<const V4*>(p)->v;
+        const uint32_t a4 = sh ? p[4] : 0u;
+        uint32_t w[4];
+        w[0] = __builtin_amdgcn_alignbyte(a.y, a.x, sh);
+        w[1] = __builtin_amdgcn_alignbyte(a.z, a.y, sh);
+        w[2] = __builtin_amdgcn_alignbyte(a.w, a.z, sh);
+        w[3] = __builtin_amdgcn_alignbyte(a4, a.w, sh);
+        const uint32_t left = len - i;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+          const uint32_t have = left > 4u * k ? left - 4u * k : 0u;   // valid bytes of word k
+          const uint32_t m = have >= 4u ? 0xFFFFFFFFu : (1u << (8u * have)) - 1u;
+          w[k] &= m;
+          seen |= w[k];
+          w[k] = swar_upper(w[k]);
+        }
+        o = u32x4{w[0], w[1], w[2], w[3]};
+      }
+      *reinterpret_cast<u32x4*>(dst + i) = o;
+    }
+    if (seen & 0x80808080u) bad[g.file] = 1u;
+  }
+}
+
+namespace {
+
+constexpr size_t kDefaultSlot = size_t(64) << 20;
+constexpr size_t kMinSlot = size_t(256) << 10;
+constexpr size_t kRampSlot = size_t(8) << 20;
+constexpr uint32_t kDefaultSlots = 4;
+constexpr size_t kMaxBatchBytes = size_t(512) << 20;
+constexpr int kBatchEvents = 64;
+
+inline size_t up256(size_t x) { return (x + 255u) & ~size_t(255); }
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Pinned { uint8_t* h = nullptr; size_t cap = 0; };
+
+// Buffers outlive an ingest: hipHostMalloc costs 130-200 ms per GB on this pool, and a process
+// (the CLI per rank, the bench, the tests) opens one ingest after the other.
+struct Cache {
+  std::mutex mu;
+  std::vector<Pinned> pinned;
+  uint8_t* d_text = nullptr; size_t d_text_cap = 0;
+  uint8_t* d_packed = nullptr; size_t d_packed_cap = 0;
+  uint8_t* d_segs = nullptr; size_t d_segs_cap = 0;
+  Pinned stage;   // segs + bad words of one batch
+  void release() {
+    std::lock_guard<std::mutex> g(mu);
+    for (Pinned& p : pinned) (void)hipHostFree(p.h);
+    pinned.clear();
+    if (stage.h) (void)hipHostFree(stage.h);
+    stage = Pinned();
+    (void)hipFree(d_text);
+    (void)hipFree(d_packed);
+    (void)hipFree(d_segs);
+    d_text = d_packed = d_segs = nullptr;
+    d_text_cap = d_packed_cap = d_segs_cap = 0;
+  }
+};
+Cache g_cache;
+
+struct FileRec {
+  int32_t status = 0;
+  uint32_t n_rows = 0, n_sites = 0;
+  uint32_t use = 0;
+  std::vector<uint64_t> row_off;    // per record: offset of its sequence run in the use's buffer (status 0)
+  std::vector<uint32_t> key_cnt;    // per key: matching records
+  std::vector<uint32_t> key_rows;   // their indices, key after key
+};
+
+// one filling of a pinned slot = one H2D copy
+struct Use {
+  uint8_t* h = nullptr;
+  uint8_t* d = nullptr;
+  size_t cap = 0, used = 0;
+  uint32_t first_pos = 0, n_pos = 0;
+  uint32_t pending = 0;   // files placed here that are still being read / indexed
+  int host_slot = -1, dev_slot = -1;
+  bool big = false, sealed = false, ready = false, enqueued = false, consumed = false;
+  hipEvent_t ev = nullptr;        // behind the copy
+  hipEvent_t repack_ev = nullptr; // behind the repack of the batch that consumed it
+};
+
+}  // namespace
+
+void ingest_release_cache() { g_cache.release(); }
+
+}  // namespace pfa
+
+struct pfa_ingest {
+  // ---- immutable after open
+  std::vector<std::string> paths;
+  std::string names_blob;
+  std::vector<uint64_t> names_off;
+  std::vector<std::string> keys;
+  uint32_t stride_align = 128, unit_flags = 0, want_threads = 0, n_slots = pfa::kDefaultSlots, n_dev_slots = 2 * pfa::kDefaultSlots;
+  size_t max_slot = pfa::kDefaultSlot;
+  int device = 0;
+
+  // ---- pipeline state (mu)
+  std::mutex mu;
+  std::condition_variable cv_work, cv_turn, cv_slot, cv_up, cv_batch, cv_consumed;
+  std::vector<uint32_t> feed;          // feed order: indices into paths
+  std::deque<pfa::FileRec> files;      // by feed position
+  bool feed_closed = false, stop = false;
+  uint32_t next_claim = 0, turn = 0;
+  std::deque<pfa::Use> uses;
+  int open_use = -1;
+  size_t slot_bytes = 0;               // decided by the first reservation
+  std::vector<pfa::Pinned> slots;      // the ring of pinned slots
+  std::vector<int> slot_user, dev_user;   // use that holds the slot, -1: free
+  uint64_t ring_seq = 0;
+  uint8_t* d_text = nullptr; size_t d_text_cap = 0;
+  uint32_t uploaded = 0, consumed = 0;    // uses whose copy is enqueued / that a batch has taken
+  std::string hard_error;
+  int hard_rc = 0;
+  std::vector<hipEvent_t> ev_pool;
+
+  std::vector<std::thread> workers;
+  std::thread uploader;
+  bool threads_started = false;
+  hipStream_t copy_stream = nullptr;
+  hipStream_t copy_streams[4] = {};   // copies alternate over `n_streams` of them (copy_stream = the first)
+  uint32_t n_streams = 1, max_inflight = 2;
+  hipEvent_t batch_ev[pfa::kBatchEvents] = {};
+  uint32_t n_batches = 0;
+
+  // ---- the current batch (caller's thread)
+  pfa_plan* plan = nullptr;
+  std::vector<uint32_t> b_file_idx, b_n_rows, b_n_sites, b_key_rows, b_unit_file, b_unit_key, b_unit_rows, b_ridx;
+  std::vector<int32_t> b_status;
+  std::vector<pfa_desc> b_descs;
+  std::vector<pfa::Pinned> big_pinned_done;   // pinned buffers of oversized files whose copy has completed
+  std::vector<uint8_t*> big_dev;              // device buffers of oversized files of the current batch
+  uint32_t* bad_words = nullptr;
+  bool launched = false;                      // something of the current batch sits on the context stream
+
+  // ---- statistics
+  std::atomic<uint64_t> ns_read{0}, ns_index{0}, bytes_read{0}, ns_copy{0}, bytes_copied{0}, ns_main{0};
+};
+
+namespace pfa {
+namespace {
+
+void fail(pfa_ingest* g, int rc, const std::string& msg) {   // mu held
+  if (g->hard_rc == 0) { g->hard_rc = rc; g->hard_error = msg; }
+  g->stop = true;
+  g->cv_work.notify_all(); g->cv_turn.notify_all(); g->cv_slot.notify_all();
+  g->cv_up.notify_all(); g->cv_batch.notify_all(); g->cv_consumed.notify_all();
+}
+
+hipEvent_t take_event(pfa_ingest* g) {   // mu held
+  if (!g->ev_pool.empty()) { hipEvent_t e = g->ev_pool.back(); g->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return e;
+}
+
+bool all_reserved(const pfa_ingest* g) { return g->turn == g->feed.size(); }
+
+void seal(pfa_ingest* g, int u) {   // mu held
+  if (u < 0) return;
+  Use& s = g->uses[(size_t)u];
+  if (s.sealed) return;
+  s.sealed = true;
+  if (s.pending == 0) { s.ready = true; g->cv_up.notify_all(); }
+}
+
+Pinned take_pinned(size_t want) {
+  {
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    size_t best = g_cache.pinned.size();
+    for (size_t i = 0; i < g_cache.pinned.size(); ++i)
+      if (g_cache.pinned[i].cap >= want && g_cache.pinned[i].cap <= 4 * want && (best == g_cache.pinned.size() || g_cache.pinned[i].cap < g_cache.pinned[best].cap)) best = i;
+    if (best != g_cache.pinned.size()) {
+      Pinned p = g_cache.pinned[best];
+      g_cache.pinned.erase(g_cache.pinned.begin() + (long)best);
+      return p;
+    }
+  }
+  Pinned p;
+  if (hipHostMalloc((void**)&p.h, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p.h = nullptr; return p; }
+  p.cap = want;
+  return p;
+}
+
+void give_pinned(Pinned p) {
+  if (!p.h) return;
+  std::lock_guard<std::mutex> lk(g_cache.mu);
+  size_t total = p.cap;
+  for (const Pinned& q : g_cache.pinned) total += q.cap;
+  if (g_cache.pinned.size() >= 16 || total > (size_t(1) << 30)) { (void)hipHostFree(p.h); return; }
+  g_cache.pinned.push_back(p);
+}
+
+// a new use for a file of `need` bytes; mu held through `lk` (released while it waits or allocates)
+int new_use(pfa_ingest* g, std::unique_lock<std::mutex>& lk, size_t need, uint32_t pos) {
+  if (g->slot_bytes == 0) {
+    // the first file sizes the ring: small inputs get small slots (a one-file run pins 256 KiB, not 64 MiB)
+    const size_t remaining = g->feed.size() - pos;
+    size_t est = need * std::max<size_t>(remaining, 1);
+    est = (est + kMinSlot - 1) / kMinSlot * kMinSlot;
+    g->slot_bytes = std::min(std::max(est, kMinSlot), g->max_slot);
+    const size_t want = (size_t)g->n_dev_slots * g->slot_bytes + 256u;
+    {
+      std::lock_guard<std::mutex> ck(g_cache.mu);
+      if (g_cache.d_text_cap >= want) { g->d_text = g_cache.d_text; g->d_text_cap = g_cache.d_text_cap; g_cache.d_text = nullptr; g_cache.d_text_cap = 0; }
+    }
+    if (!g->d_text) {
+      if (hipMalloc((void**)&g->d_text, want) != hipSuccess) { (void)hipGetLastError(); fail(g, PFA_ERR_NOMEM, "ingest: cannot allocate the device text ring"); return -1; }
+      g->d_text_cap = want;
+    }
+  }
+  Use u;
+  u.first_pos = pos;
+  if (need > g->slot_bytes) {   // a file larger than a slot travels alone, in buffers of its own
+    u.big = true;
+    lk.unlock();
+    Pinned p = take_pinned(need);
+    uint8_t* d = nullptr;
+    const bool ok = p.h && hipMalloc((void**)&d, need + 256u) == hipSuccess;
+    lk.lock();
+    if (!ok) { (void)hipGetLastError(); give_pinned(p); fail(g, PFA_ERR_NOMEM, "ingest: cannot allocate buffers for a " + std::to_string(need) + "-byte file"); return -1; }
+    u.h = p.h; u.cap = p.cap; u.d = d;
+  } else {
+    const int hs = (int)(g->ring_seq % g->n_slots);
+    const int ds = (int)(g->ring_seq % g->n_dev_slots);
+    g->ring_seq += 1;
+    while (!g->stop && g->slot_user[(size_t)hs] >= 0) g->cv_slot.wait(lk);   // its last copy is still in flight
+    if (g->stop) return -1;
+    if (!g->slots[(size_t)hs].h) {
+      lk.unlock();
+      Pinned p = take_pinned(g->slot_bytes);
+      lk.lock();
+      if (!p.h) { fail(g, PFA_ERR_NOMEM, "ingest: cannot allocate a pinned slot"); return -1; }
+      g->slots[(size_t)hs] = p;
+    }
+    u.h = g->slots[(size_t)hs].h;
+    // the first slots are closed early (8, 16, 32 MiB): the link starts on the first few files, not on the first 64 MiB
+    u.cap = std::min(g->slot_bytes, std::max(need, kRampSlot << std::min<uint64_t>(g->ring_seq - 1, 8)));
+    u.host_slot = hs;
+    u.dev_slot = ds;
+    u.d = g->d_text + (size_t)ds * g->slot_bytes;
+  }
+  u.ev = take_event(g);
+  if (!u.ev) { fail(g, PFA_ERR_HIP, "ingest: hipEventCreate failed"); return -1; }
+  g->uses.push_back(u);
+  const int idx = (int)g->uses.size() - 1;
+  if (u.host_slot >= 0) g->slot_user[(size_t)u.host_slot] = idx;
+  return idx;
+}
+
+// the file of feed position `pos` gets `size` bytes in the pinned ring (in feed order: batches are
+// consecutive runs of it); returns its use and offset, or false when the ingest is stopping
+bool reserve(pfa_ingest* g, uint32_t pos, size_t size, uint32_t* use_out, size_t* off_out, uint8_t** text_out) {
+  const size_t need = up256(std::max<size_t>(size, 1));
+  std::unique_lock<std::mutex> lk(g->mu);
+  while (!g->stop && g->turn != pos) g->cv_turn.wait(lk);
+  if (g->stop) return false;
+  int u = g->open_use;
+  if (u < 0 || need > g->slot_bytes || g->uses[(size_t)u].used + need > g->uses[(size_t)u].cap) {
+    seal(g, g->open_use);
+    g->open_use = -1;
+    u = new_use(g, lk, need, pos);
+    if (u < 0) return false;
+    if (!g->uses[(size_t)u].big) g->open_use = u;
+  }
+  Use& s = g->uses[(size_t)u];
+  *use_out = (uint32_t)u;
+  *off_out = s.used;
+  *text_out = s.h + s.used;
+  s.used += need;
+  s.pending += 1;
+  s.n_pos += 1;
+  g->files[pos].use = (uint32_t)u;
+  if (s.big) seal(g, u);
+  g->turn += 1;
+  // nothing further to place for now: let what has been read travel (a rank between two claims
+  // of the shared queue must not sit on a half-filled slot)
+  if (all_reserved(g)) { seal(g, g->open_use); g->open_use = -1; }
+  g->cv_turn.notify_all();
+  return true;
+}
+
+void finish(pfa_ingest* g, uint32_t use) {
+  std::lock_guard<std::mutex> lk(g->mu);
+  Use& s = g->uses[use];
+  s.pending -= 1;
+  if (s.sealed && s.pending == 0) { s.ready = true; g->cv_up.notify_all(); }
+}
+
+void worker_body(pfa_ingest* g) {
+  (void)hipSetDevice(g->device);
+  IndexScratch sc;
+  std::vector<pfa_fasta_row> rows;
+  for (;;) {
+    uint32_t pos;
+    FileRec* fp;
+    uint32_t path_idx;
+    {
+      // (the containers grow under the lock: element addresses are taken under it as well)
+      std::unique_lock<std::mutex> lk(g->mu);
+      while (!g->stop && g->next_claim >= g->feed.size() && !g->feed_closed) g->cv_work.wait(lk);
+      if (g->stop || g->next_claim >= g->feed.size()) return;
+      pos = g->next_claim++;
+      fp = &g->files[pos];
+      path_idx = g->feed[pos];
+    }
+    FileRec& f = *fp;
+    const std::string& path = g->paths[path_idx];
+    int fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    size_t size = 0;
+    if (fd >= 0) {
+      // only regular files have a size to trust (a directory opens fine)
+      struct stat sb;
+      if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 0 || (uint64_t)sb.st_size > (1ull << 40)) { close(fd); fd = -1; }
+      else size = (size_t)sb.st_size;
+    }
+    if (fd < 0) f.status = PFA_ERR_IO;
+    uint32_t use = 0;
+    size_t off = 0;
+    uint8_t* text = nullptr;
+    if (!reserve(g, pos, size, &use, &off, &text)) { if (fd >= 0) close(fd); return; }
+    if (fd >= 0) {
+      const double t0 = now_s();
+      size_t got = 0;
+      while (got < size) {
+        const ssize_t r = read(fd, text + got, size - got);
+        if (r <= 0) break;
+        got += (size_t)r;
+      }
+      close(fd);
+      if (got != size) f.status = PFA_ERR_IO;
+      const double t1 = now_s();
+      g->ns_read += (uint64_t)((t1 - t0) * 1e9);
+      g->bytes_read += got;
+      if (f.status == 0) {
+        const int64_t n = index_compact(text, size, rows, sc);
+        if (n == PFA_ERR_FORMAT && strncmp(pfa_last_error(), "not FASTA", 9) == 0) {
+          f.status = PFA_FILE_NOT_FASTA;
+        } else if (n < 0) {
+          std::lock_guard<std::mutex> lk(g->mu);
+          fail(g, (int)n, path + ": " + pfa_last_error());
+        } else {
+          f.n_rows = (uint32_t)n;
+          f.n_sites = n ? rows[0].seq_len : 0u;
+          for (const pfa_fasta_row& r : rows)
+            if (r.seq_len != f.n_sites) { f.status = PFA_FILE_UNEQUAL; break; }   // PolyFastA.py:111-112
+          if (f.status == 0) {
+            f.row_off.resize(rows.size());
+            for (size_t i = 0; i < rows.size(); ++i) f.row_off[i] = off + rows[i].seq_off;
+            if (!g->keys.empty()) {   // PolyFastA.py:125: `pop in header`, a substring match, in record order
+              f.key_cnt.assign(g->keys.size(), 0u);
+              for (size_t k = 0; k < g->keys.size(); ++k) {
+                const std::string& key = g->keys[k];
+                for (size_t i = 0; i < rows.size(); ++i) {
+                  const char* nm = reinterpret_cast<const char*>(text + rows[i].name_off);
+                  if (key.empty() || memmem(nm, rows[i].name_len, key.data(), key.size()) != nullptr) {
+                    f.key_rows.push_back((uint32_t)i);
+                    f.key_cnt[k] += 1;
+                  }
+                }
+              }
+            }
+          }
+        }
+        g->ns_index += (uint64_t)((now_s() - t1) * 1e9);
+      }
+    }
+    finish(g, use);
+  }
+}
+
+void worker(pfa_ingest* g) {
+  try {
+    worker_body(g);
+  } catch (const std::bad_alloc&) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    fail(g, PFA_ERR_NOMEM, "ingest: out of host memory");
+  } catch (...) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    fail(g, PFA_ERR_ARG, "ingest: unexpected exception in a loader thread");
+  }
+}
+
+void uploader_body(pfa_ingest* g) {
+  (void)hipSetDevice(g->device);
+  uint32_t next_up = 0;
+  std::deque<uint32_t> inflight;
+  double t_busy0 = 0.0;
+  std::unique_lock<std::mutex> lk(g->mu);
+  auto reap = [&]() {   // wait for the oldest copy; its pinned slot is free again
+    const uint32_t u = inflight.front();
+    hipEvent_t ev = g->uses[u].ev;
+    lk.unlock();
+    const hipError_t e = hipEventSynchronize(ev);
+    lk.lock();
+    if (e != hipSuccess) { fail(g, PFA_ERR_HIP, std::string("ingest: H2D copy failed: ") + hipGetErrorString(e)); return; }
+    Use& s = g->uses[u];
+    if (s.host_slot >= 0) { g->slot_user[(size_t)s.host_slot] = -1; g->cv_slot.notify_all(); }
+    else g->big_pinned_done.push_back(Pinned{s.h, s.cap});
+    inflight.pop_front();
+    if (inflight.empty()) g->ns_copy += (uint64_t)((now_s() - t_busy0) * 1e9);
+  };
+  for (;;) {
+    if (g->stop) break;
+    const bool have = next_up < g->uses.size() && g->uses[next_up].ready;
+    if (have && inflight.size() < g->max_inflight) {
+      Use& s = g->uses[next_up];
+      hipEvent_t wait_ev = nullptr;
+      if (!s.big) {
+        // the device slot's previous text must have been repacked (its batch taken by the caller)
+        const int prev = g->dev_user[(size_t)s.dev_slot];
+        if (prev >= 0 && !g->uses[(size_t)prev].consumed) {
+          if (!inflight.empty()) { reap(); continue; }
+          g->cv_consumed.wait(lk);
+          continue;
+        }
+        if (prev >= 0) wait_ev = g->uses[(size_t)prev].repack_ev;
+        g->dev_user[(size_t)s.dev_slot] = (int)next_up;
+      }
+      uint8_t* const d = s.d;
+      uint8_t* const h = s.h;
+      const size_t n = s.used;
+      hipEvent_t ev = s.ev;
+      hipStream_t cs = g->copy_streams[next_up % g->n_streams];
+      lk.unlock();
+      hipError_t e = hipSuccess;
+      if (wait_ev) e = hipStreamWaitEvent(cs, wait_ev, 0);
+      if (e == hipSuccess && n) e = hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, cs);
+      if (e == hipSuccess) e = hipEventRecord(ev, cs);
+      lk.lock();
+      if (e != hipSuccess) { fail(g, PFA_ERR_HIP, std::string("ingest: cannot enqueue an H2D copy: ") + hipGetErrorString(e)); break; }
+      if (inflight.empty()) t_busy0 = now_s();
+      g->bytes_copied += n;
+      g->uses[next_up].enqueued = true;
+      inflight.push_back(next_up);
+      next_up += 1;
+      g->uploaded = next_up;
+      g->cv_batch.notify_all();
+      continue;
+    }
+    if (!inflight.empty()) { reap(); continue; }
+    if (g->feed_closed && all_reserved(g) && next_up == g->uses.size()) break;   // everything is on the card
+    g->cv_up.wait(lk);
+  }
+  while (!inflight.empty() && g->hard_rc == 0) reap();
+}
+
+void uploader(pfa_ingest* g) {
+  try {
+    uploader_body(g);
+  } catch (...) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    fail(g, PFA_ERR_ARG, "ingest: unexpected exception in the uploader thread");
+  }
+}
+
+uint32_t auto_threads() {
+  if (const char* e = getenv("PFA_THREADS")) { const long v = strtol(e, nullptr, 10); if (v > 0) return (uint32_t)std::min<long>(v, 256); }
+  cpu_set_t set;
+  uint32_t cpus = 1;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = (uint32_t)std::max(1, CPU_COUNT(&set));
+  uint32_t local = 1;
+  for (const char* var : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
+    if (const char* e = getenv(var)) { const long v = strtol(e, nullptr, 10); if (v > 0) { local = (uint32_t)v; break; } }
+  return std::max(1u, std::min(16u, cpus / std::max(local, 1u)));
+}
+
+int ensure_dev(uint8_t** p, size_t* cap, size_t need) {
+  if (*cap >= need) return PFA_OK;
+  if (*p) { PFA_HIP(hipStreamSynchronize(ctx().stream)); PFA_HIP(hipFree(*p)); }
+  *p = nullptr;
+  *cap = 0;
+  const size_t want = need + need / 4 + 4096;
+  PFA_HIP(hipMalloc((void**)p, want));
+  *cap = want;
+  return PFA_OK;
+}
+
+}  // namespace
+}  // namespace pfa
+
+extern "C" {
+
+int pfa_ingest_open(const char* const* paths, uint32_t n_files, const pfa_ingest_opts* opts, pfa_ingest** out) {
+  PFA_NEED_INIT();
+  if (!out || (n_files && !paths)) { pfa::set_error("pfa_ingest_open: NULL argument"); return PFA_ERR_ARG; }
+  *out = nullptr;
+  pfa_ingest_opts o{};
+  if (opts) o = *opts;
+  if (o.stride_align == 0) o.stride_align = 128;
+  if (o.stride_align < 16 || (o.stride_align & (o.stride_align - 1))) { pfa::set_error("pfa_ingest_open: stride_align must be a power of two >= 16"); return PFA_ERR_ARG; }
+  if (o.unit_flags & ~PFA_FLAG_CDS) { pfa::set_error("pfa_ingest_open: unknown unit flags 0x%x", o.unit_flags); return PFA_ERR_ARG; }
+  if (o.n_keys && !o.keys) { pfa::set_error("pfa_ingest_open: keys is NULL"); return PFA_ERR_ARG; }
+  pfa_ingest* g = nullptr;
+  try {
+    g = new pfa_ingest();
+    g->paths.reserve(n_files);
+    g->names_off.reserve((size_t)n_files + 1);
+    g->names_off.push_back(0);
+    for (uint32_t i = 0; i < n_files; ++i) {
+      if (!paths[i]) { delete g; pfa::set_error("pfa_ingest_open: path %u is NULL", i); return PFA_ERR_ARG; }
+      g->paths.emplace_back(paths[i]);
+      const std::string& p = g->paths.back();
+      const size_t sl = p.rfind('/');                        // display name = text after the last '/' (PolyFastA.py:110)
+      g->names_blob.append(p, sl == std::string::npos ? 0 : sl + 1, std::string::npos);
+      g->names_off.push_back(g->names_blob.size());
+    }
+    for (uint32_t k = 0; k < o.n_keys; ++k) g->keys.emplace_back(o.keys[k] ? o.keys[k] : "");
+    g->stride_align = o.stride_align;
+    g->unit_flags = o.unit_flags;
+    g->want_threads = o.n_threads ? std::min(o.n_threads, 256u) : pfa::auto_threads();
+    g->n_slots = o.n_slots ? std::min(std::max(o.n_slots, 2u), 64u) : pfa::kDefaultSlots;
+    g->n_dev_slots = 2 * g->n_slots;
+    g->max_slot = o.slot_bytes ? std::max<size_t>(pfa::up256((size_t)o.slot_bytes), 4096) : pfa::kDefaultSlot;
+    if (const char* e = getenv("PFA_INGEST_SLOTS")) { const long v = strtol(e, nullptr, 10); if (v >= 2 && v <= 64) { g->n_slots = (uint32_t)v; g->n_dev_slots = 2 * g->n_slots; } }
+    if (const char* e = getenv("PFA_INGEST_SLOT_BYTES")) { const long long v = strtoll(e, nullptr, 10); if (v > 0) g->max_slot = std::max<size_t>(pfa::up256((size_t)v), 4096); }
+    g->device = pfa::ctx().device;
+    g->slots.assign(g->n_slots, pfa::Pinned());
+    g->slot_user.assign(g->n_slots, -1);
+    g->dev_user.assign(g->n_dev_slots, -1);
+  } catch (const std::bad_alloc&) {
+    delete g;
+    pfa::set_error("pfa_ingest_open: out of host memory");
+    return PFA_ERR_NOMEM;
+  }
+  if (const char* e = getenv("PFA_INGEST_INFLIGHT")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 16) g->max_inflight = (uint32_t)v; }
+  if (const char* e = getenv("PFA_INGEST_STREAMS")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 4) g->n_streams = (uint32_t)v; }
+  for (uint32_t k = 0; k < g->n_streams; ++k)
+    if (hipStreamCreateWithFlags(&g->copy_streams[k], hipStreamNonBlocking) != hipSuccess) {
+      for (uint32_t j = 0; j < k; ++j) (void)hipStreamDestroy(g->copy_streams[j]);
+      delete g;
+      pfa::set_error("pfa_ingest_open: cannot create the copy stream");
+      return PFA_ERR_HIP;
+    }
+  g->copy_stream = g->copy_streams[0];
+  *out = g;
+  return PFA_OK;
+}
+
+int pfa_ingest_feed(pfa_ingest* g, const uint32_t* file_idx, uint32_t n, int last) {
+  PFA_NEED_INIT();
+  if (!g) { pfa::set_error("pfa_ingest_feed: ingest is NULL"); return PFA_ERR_ARG; }
+  try {
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->feed_closed) { pfa::set_error("pfa_ingest_feed: the feed was closed by an earlier call"); return PFA_ERR_ARG; }
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t f = file_idx ? file_idx[i] : i;
+      if (f >= g->paths.size()) { pfa::set_error("pfa_ingest_feed: file index %u >= %zu", f, g->paths.size()); return PFA_ERR_ARG; }
+      g->feed.push_back(f);
+      g->files.emplace_back();
+    }
+    if (last) g->feed_closed = true;
+    if (!g->threads_started && (!g->feed.empty() || g->feed_closed)) {
+      g->threads_started = true;
+      const uint32_t nt = std::max(1u, std::min<uint32_t>(g->want_threads, (uint32_t)std::max<size_t>(g->feed.size(), 1)));
+      g->want_threads = nt;
+      for (uint32_t t = 0; t < nt; ++t) g->workers.emplace_back(pfa::worker, g);
+      g->uploader = std::thread(pfa::uploader, g);
+    }
+    g->cv_work.notify_all();
+    g->cv_up.notify_all();
+    g->cv_batch.notify_all();
+  } catch (...) {
+    pfa::set_error("pfa_ingest_feed: cannot start the loader threads");
+    return PFA_ERR_NOMEM;
+  }
+  return PFA_OK;
+}
+
+uint32_t pfa_ingest_backlog(const pfa_ingest* g) {
+  if (!g) return 0;
+  pfa_ingest* m = const_cast<pfa_ingest*>(g);
+  std::lock_guard<std::mutex> lk(m->mu);
+  uint32_t handed = 0;
+  if (g->consumed) { const pfa::Use& u = g->uses[g->consumed - 1]; handed = u.first_pos + u.n_pos; }
+  return (uint32_t)g->feed.size() - handed;
+}
+
+static void release_batch(pfa_ingest* g) {
+  if (g->plan) { pfa_plan_destroy(g->plan); g->plan = nullptr; }   // synchronises the stream: the last repack is done
+  else if (g->launched && pfa::ctx().ready) (void)hipStreamSynchronize(pfa::ctx().stream);
+  g->launched = false;
+  for (uint8_t* d : g->big_dev) (void)hipFree(d);
+  g->big_dev.clear();
+  std::vector<pfa::Pinned> done;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    done.swap(g->big_pinned_done);
+  }
+  for (pfa::Pinned& p : done) pfa::give_pinned(p);
+}
+
+int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
+  PFA_NEED_INIT();
+  if (!g || !out) { pfa::set_error("pfa_ingest_next: NULL argument"); return PFA_ERR_ARG; }
+  memset(out, 0, sizeof(*out));
+  release_batch(g);
+  const double t_in = pfa::now_s();
+  uint32_t lo, hi;
+  struct View { uint8_t* d; bool big; uint32_t first_pos, n_pos; hipEvent_t ev; };
+  std::vector<View> uv;
+  {
+    std::unique_lock<std::mutex> lk(g->mu);
+    for (;;) {
+      if (g->hard_rc) { pfa::set_error("%s", g->hard_error.c_str()); return g->hard_rc; }
+      if (g->consumed < g->uploaded) break;
+      if (g->feed_closed && pfa::all_reserved(g) && g->consumed == g->uses.size()) return 0;
+      if (!g->threads_started) { pfa::set_error("pfa_ingest_next: nothing has been fed"); return PFA_ERR_ARG; }
+      if (!g->feed_closed && pfa::all_reserved(g) && g->consumed == g->uses.size()) {
+        pfa::set_error("pfa_ingest_next: every fed file has been handed out and the feed is still open");
+        return PFA_ERR_ARG;
+      }
+      g->cv_batch.wait(lk);
+    }
+    lo = g->consumed;
+    hi = lo + 1;
+    if (!g->uses[lo].big) {
+      size_t bytes = g->uses[lo].used;
+      while (hi < g->uploaded && !g->uses[hi].big && bytes + g->uses[hi].used <= pfa::kMaxBatchBytes) { bytes += g->uses[hi].used; ++hi; }
+    }
+    for (uint32_t u = lo; u < hi; ++u) uv.push_back(View{g->uses[u].d, g->uses[u].big, g->uses[u].first_pos, g->uses[u].n_pos, g->uses[u].ev});
+  }
+  try {
+    const uint32_t p0 = uv.front().first_pos, p1 = uv.back().first_pos + uv.back().n_pos;
+    const uint32_t nf = p1 - p0, nk = (uint32_t)g->keys.size();
+    g->b_file_idx.resize(nf); g->b_status.resize(nf); g->b_n_rows.resize(nf); g->b_n_sites.resize(nf);
+    g->b_key_rows.assign((size_t)nf * nk, 0u);
+    g->b_unit_file.clear(); g->b_unit_key.clear(); g->b_unit_rows.clear(); g->b_ridx.clear(); g->b_descs.clear();
+    bool regular = true;
+    uint64_t packed = 0, n_segs = 0;
+    for (uint32_t b = 0; b < nf; ++b) {
+      const pfa::FileRec& f = g->files[p0 + b];
+      g->b_file_idx[b] = g->feed[p0 + b];
+      g->b_status[b] = f.status;
+      g->b_n_rows[b] = f.n_rows;
+      g->b_n_sites[b] = f.n_sites;
+      if (f.status != 0) { regular = false; continue; }
+      if ((g->unit_flags & PFA_FLAG_CDS) && f.n_sites % 3u != 0u) regular = false;
+      n_segs += f.n_sites ? f.n_rows : 0u;
+    }
+    // staging: the segments and the per-file `bad` words of this batch, in pinned memory
+    const size_t seg_bytes = (size_t)n_segs * sizeof(pfa::Seg), bad_off = pfa::up256(seg_bytes), stage_need = bad_off + pfa::up256((size_t)nf * 4u + 4u);
+    {
+      std::lock_guard<std::mutex> ck(pfa::g_cache.mu);
+      if (pfa::g_cache.stage.cap < stage_need) {
+        if (pfa::g_cache.stage.h) (void)hipHostFree(pfa::g_cache.stage.h);
+        pfa::g_cache.stage = pfa::Pinned();
+        const size_t want = stage_need + stage_need / 2 + 65536;
+        if (hipHostMalloc((void**)&pfa::g_cache.stage.h, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pfa::set_error("pfa_ingest_next: cannot allocate the staging buffer"); return PFA_ERR_NOMEM; }
+        pfa::g_cache.stage.cap = want;
+      }
+    }
+    pfa::Seg* const h_segs = reinterpret_cast<pfa::Seg*>(pfa::g_cache.stage.h);
+    g->bad_words = reinterpret_cast<uint32_t*>(pfa::g_cache.stage.h + bad_off);
+    memset(g->bad_words, 0, (size_t)nf * 4u + 4u);
+    const uint8_t* const text_base = uv.front().big ? uv.front().d : g->d_text;
+    uint64_t si = 0;
+    for (uint32_t b = 0; b < nf; ++b) {
+      const pfa::FileRec& f = g->files[p0 + b];
+      if (f.status != 0) continue;
+      const uint64_t stride = std::max<uint64_t>(16, ((uint64_t)f.n_sites + g->stride_align - 1) & ~uint64_t(g->stride_align - 1));
+      if (stride > 0xFFFFFFF0ull) { pfa::set_error("pfa_ingest_next: %s: sequences too long", g->paths[g->b_file_idx[b]].c_str()); return PFA_ERR_ARG; }
+      const uint64_t base = packed;
+      packed += pfa::up256((size_t)(std::max<uint64_t>(f.n_rows, 1) * stride));
+      if (f.n_sites) {
+        const uint64_t use_off = (uint64_t)(uv[f.use - lo].d - text_base);
+        for (uint32_t r = 0; r < f.n_rows; ++r) h_segs[si++] = pfa::Seg{use_off + f.row_off[r], base + (uint64_t)r * stride, f.n_sites, b};
+      }
+      pfa_desc d{};
+      d.base_off = base;
+      d.n_sites = f.n_sites;
+      d.row_stride = (uint32_t)stride;
+      d.flags = g->unit_flags;
+      d.mat_rows = f.n_rows;
+      if (nk == 0) {
+        d.n_rows = f.n_rows;
+        d.row_idx_off = PFA_NO_ROW_IDX;
+        g->b_descs.push_back(d);
+        g->b_unit_file.push_back(b); g->b_unit_key.push_back(PFA_NO_KEY); g->b_unit_rows.push_back(f.n_rows);
+      } else {
+        size_t at = 0;
+        for (uint32_t k = 0; k < nk; ++k) {
+          const uint32_t c = f.key_cnt[k];
+          g->b_key_rows[(size_t)b * nk + k] = c;
+          if (c == 0) { regular = false; continue; }               // "# Pop X string was not found" (PolyFastA.py:126-131)
+          d.n_rows = c;
+          d.row_idx_off = (uint32_t)g->b_ridx.size();
+          g->b_ridx.insert(g->b_ridx.end(), f.key_rows.begin() + (long)at, f.key_rows.begin() + (long)(at + c));
+          at += c;
+          g->b_descs.push_back(d);
+          g->b_unit_file.push_back(b); g->b_unit_key.push_back(k); g->b_unit_rows.push_back(c);
+        }
+      }
+    }
+    // sfs_off / tile_off: prefix sums in unit order (the plan's bitmap / SFS geometry)
+    {
+      uint64_t sfs = 0, tiles = 0;
+      for (pfa_desc& d : g->b_descs) {
+        if (sfs > 0xFFFFFFFFull || tiles > 0xFFFFFFFFull) { pfa::set_error("pfa_ingest_next: batch too large for 32-bit SFS / tile offsets"); return PFA_ERR_ARG; }
+        d.sfs_off = (uint32_t)sfs;
+        d.tile_off = (uint32_t)tiles;
+        sfs += d.n_rows / 2u;
+        tiles += (d.n_rows && d.n_sites) ? ((uint64_t)d.n_sites + PFA_TILE_SITES - 1u) / PFA_TILE_SITES : 0u;
+      }
+    }
+    const uint32_t nu = (uint32_t)g->b_descs.size();
+    hipStream_t st = pfa::ctx().stream;
+    int rc = PFA_OK;
+    if (nu) {
+      rc = pfa_plan_create(g->b_descs.data(), nu, g->b_ridx.empty() ? nullptr : g->b_ridx.data(), g->b_ridx.size(), packed, 0u, &g->plan);
+      if (rc != PFA_OK) return rc;
+    }
+    {
+      std::lock_guard<std::mutex> ck(pfa::g_cache.mu);
+      rc = pfa::ensure_dev(&pfa::g_cache.d_packed, &pfa::g_cache.d_packed_cap, (size_t)packed + 256u);
+      if (rc == PFA_OK) rc = pfa::ensure_dev(&pfa::g_cache.d_segs, &pfa::g_cache.d_segs_cap, seg_bytes + 256u);
+    }
+    if (rc != PFA_OK) return rc;
+    // everything below is enqueued behind the copies of this batch's slots
+    // (copies of one stream complete in order; with several copy streams every slot's event is waited for)
+    for (size_t k = g->n_streams > 1 ? 0 : uv.size() - 1; k < uv.size(); ++k) PFA_HIP(hipStreamWaitEvent(st, uv[k].ev, 0));
+    g->launched = true;
+    if (n_segs) {
+      uint32_t* d_bad = nullptr;
+      PFA_HIP(hipHostGetDevicePointer((void**)&d_bad, g->bad_words, 0));
+      PFA_HIP(hipMemcpyAsync(pfa::g_cache.d_segs, h_segs, seg_bytes, hipMemcpyHostToDevice, st));
+      const unsigned blocks = (unsigned)std::min<uint64_t>(n_segs, 1u << 20);
+      hipLaunchKernelGGL(pfa::repack_kernel, dim3(blocks), dim3(256), 0, st, text_base, reinterpret_cast<const pfa::Seg*>(pfa::g_cache.d_segs),
+                         (uint32_t)std::min<uint64_t>(n_segs, 0xFFFFFFFFull), pfa::g_cache.d_packed, g->stride_align, d_bad);
+      PFA_HIP(hipGetLastError());
+    }
+    hipEvent_t& bev = g->batch_ev[g->n_batches % pfa::kBatchEvents];
+    if (!bev) PFA_HIP(hipEventCreateWithFlags(&bev, hipEventDisableTiming));
+    PFA_HIP(hipEventRecord(bev, st));
+    if (g->plan) {
+      rc = pfa_plan_run(g->plan, pfa::g_cache.d_packed, 0);
+      if (rc != PFA_OK) return rc;
+    }
+    {
+      std::lock_guard<std::mutex> lk(g->mu);
+      for (uint32_t u = lo; u < hi; ++u) {
+        g->uses[u].consumed = true;
+        g->uses[u].repack_ev = bev;
+        if (g->uses[u].big) g->big_dev.push_back(g->uses[u].d);
+        // the rows of these files are on their way: their tables can go
+        for (uint32_t p = g->uses[u].first_pos; p < g->uses[u].first_pos + g->uses[u].n_pos; ++p) {
+          pfa::FileRec& f = g->files[p];
+          std::vector<uint64_t>().swap(f.row_off);
+          std::vector<uint32_t>().swap(f.key_rows);
+        }
+      }
+      g->consumed = hi;
+      g->cv_consumed.notify_all();
+    }
+    g->n_batches += 1;
+    out->n_files = nf;
+    out->n_units = nu;
+    out->first_pos = p0;
+    out->flags = regular ? PFA_BATCH_REGULAR : 0u;
+    out->file_idx = g->b_file_idx.data();
+    out->status = g->b_status.data();
+    out->n_rows = g->b_n_rows.data();
+    out->n_sites = g->b_n_sites.data();
+    out->key_rows = g->b_key_rows.data();
+    out->unit_file = g->b_unit_file.data();
+    out->unit_key = g->b_unit_key.data();
+    out->unit_rows = g->b_unit_rows.data();
+    out->bad_bytes = g->bad_words;
+    out->plan = g->plan;
+  } catch (const std::bad_alloc&) {
+    pfa::set_error("pfa_ingest_next: out of host memory");
+    return PFA_ERR_NOMEM;
+  }
+  g->ns_main += (uint64_t)((pfa::now_s() - t_in) * 1e9);
+  return 1;
+}
+
+int pfa_ingest_names(const pfa_ingest* g, const char** blob, const uint64_t** off) {
+  if (!g || !blob || !off) { pfa::set_error("pfa_ingest_names: NULL argument"); return PFA_ERR_ARG; }
+  *blob = g->names_blob.data();
+  *off = g->names_off.data();
+  return PFA_OK;
+}
+
+int pfa_ingest_stats(const pfa_ingest* g, double* out8) {
+  if (!g || !out8) { pfa::set_error("pfa_ingest_stats: NULL argument"); return PFA_ERR_ARG; }
+  out8[0] = (double)g->ns_read.load() * 1e-9;
+  out8[1] = (double)g->ns_index.load() * 1e-9;
+  out8[2] = (double)g->bytes_read.load();
+  out8[3] = (double)g->ns_copy.load() * 1e-9;
+  out8[4] = (double)g->bytes_copied.load();
+  out8[5] = (double)g->want_threads;
+  out8[6] = (double)g->ns_main.load() * 1e-9;
+  out8[7] = (double)g->n_batches;
+  return PFA_OK;
+}
+
+void pfa_ingest_close(pfa_ingest* g) {
+  if (!g) return;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->stop = true;
+    g->cv_work.notify_all(); g->cv_turn.notify_all(); g->cv_slot.notify_all();
+    g->cv_up.notify_all(); g->cv_batch.notify_all(); g->cv_consumed.notify_all();
+  }
+  for (std::thread& t : g->workers) if (t.joinable()) t.join();
+  if (g->uploader.joinable()) g->uploader.join();
+  const bool live = pfa::ctx().ready;
+  if (live) {
+    for (uint32_t k = 0; k < g->n_streams; ++k) (void)hipStreamSynchronize(g->copy_streams[k]);
+    release_batch(g);
+    (void)hipStreamSynchronize(pfa::ctx().stream);
+  }
+  for (pfa::Use& u : g->uses) {
+    if (u.ev) (void)hipEventDestroy(u.ev);
+    if (u.big) {   // oversized files that never reached a batch
+      if (!u.consumed) (void)hipFree(u.d);
+      bool given = false;
+      for (pfa::Pinned& p : g->big_pinned_done) given = given || p.h == u.h;
+      if (!given && u.h) g->big_pinned_done.push_back(pfa::Pinned{u.h, u.cap});
+    }
+  }
+  for (hipEvent_t e : g->ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : g->batch_ev) if (e) (void)hipEventDestroy(e);
+  for (pfa::Pinned& p : g->big_pinned_done) pfa::give_pinned(p);
+  for (pfa::Pinned& p : g->slots) pfa::give_pinned(p);
+  if (g->d_text) {
+    std::lock_guard<std::mutex> ck(pfa::g_cache.mu);
+    if (live && pfa::g_cache.d_text_cap < g->d_text_cap) {
+      if (pfa::g_cache.d_text) (void)hipFree(pfa::g_cache.d_text);
+      pfa::g_cache.d_text = g->d_text;
+      pfa::g_cache.d_text_cap = g->d_text_cap;
+    } else {
+      (void)hipFree(g->d_text);
+    }
+  }
+  for (uint32_t k = 0; k < g->n_streams; ++k) if (g->copy_streams[k]) (void)hipStreamDestroy(g->copy_streams[k]);
+  delete g;
+}
+
+}  // extern "C"

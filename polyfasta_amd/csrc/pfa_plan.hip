@@ -256,6 +256,7 @@ void pfa_shutdown(void) {
   if (!c.ready) return;
   (void)hipStreamSynchronize(c.stream);
   pfa::g_pool.clear();
+  pfa::ingest_release_cache();
   (void)hipStreamDestroy(c.stream);
   c = pfa::Context();
 }

@@ -71,18 +71,36 @@ def shard_indices(n_items: int, rank: int, world: int, sizes=None):
 
 class WorkQueue:
     """The `--dir` loop as a work queue shared by the ranks of one node (north_star: "an
-    embarrassingly-parallel work queue"): the items, largest first, are claimed a few at a time
-    through a counter in a file next to the rendezvous file (`flock`); a rank that finishes early
-    simply claims more, so neither skewed file sizes nor a slow GPU decide the job time.  Which rank
-    scanned a file does not matter to the output: rank 0 orders the rows by file index."""
+    embarrassingly-parallel work queue"): the items are claimed a few at a time through a counter
+    in a file next to the rendezvous file (`flock`); a rank that finishes early simply claims more,
+    so neither skewed file sizes nor a slow GPU decide the job time.  Which rank scanned a file does
+    not matter to the output: rank 0 orders the rows by file index.
 
-    def __init__(self, sizes, world: int, path=None):
-        self.order = sorted(range(len(sizes)), key=lambda i: (-int(sizes[i]), i))
+    `items`: a count — the claim order is the item order, identical on every rank by construction
+    (the CLI: the sorted path list, no stat() of 100 k files per rank) — or a list of sizes, claimed
+    largest first (callers that know their sizes and that every rank sees the same ones).
+
+    The counter file carries no state of an earlier job: a file older than this job's launcher is
+    emptied under the lock before the first claim (the same rule as the unique-id file)."""
+
+    def __init__(self, items, world: int, path=None):
+        if isinstance(items, int):
+            self.order = list(range(items))
+        else:
+            self.order = sorted(range(len(items)), key=lambda i: (-int(items[i]), i))
         self.world = max(int(world), 1)
         # a claim = 1/(4 world) of the items at most: even a small directory is spread over the ranks
         self.grain = max(1, min(512, len(self.order) // (4 * self.world)))
         self.path = path or rendezvous_path() + ".queue"
         self.fd = os.open(self.path, os.O_RDWR | os.O_CREAT, 0o600)     # empty file = nothing claimed yet
+        import fcntl
+        fcntl.flock(self.fd, fcntl.LOCK_EX)
+        try:
+            t_launcher = _parent_start_time()
+            if t_launcher and os.fstat(self.fd).st_mtime < t_launcher - 1.0:
+                os.ftruncate(self.fd, 0)          # left behind by a job whose rank 0 died before its unlink
+        finally:
+            fcntl.flock(self.fd, fcntl.LOCK_UN)
 
     def claim(self):
         """the next item indices of this rank ([] when the queue is drained)"""
@@ -107,6 +125,94 @@ class WorkQueue:
         if unlink:
             with contextlib.suppress(OSError):
                 os.unlink(self.path)
+
+
+def single_node(world: int) -> bool:
+    """The work queue and the unique-id rendezvous are files of ONE node: a launcher that spreads the
+    ranks over several nodes (LOCAL_WORLD_SIZE < WORLD_SIZE) is refused by the CLI and the bench."""
+    local = os.environ.get("LOCAL_WORLD_SIZE")
+    return local is None or int(local) == int(world)
+
+
+# ---------------------------------------------------------------- CPU affinity
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            cpus.update(range(int(a), int(b) + 1))
+        elif part:
+            cpus.add(int(part))
+    return sorted(cpus)
+
+
+def gpu_local_cpus(local_rank: int, kfd_root="/sys/class/kfd/kfd/topology/nodes", pci_root="/sys/bus/pci/devices",
+                   drm_root="/sys/class/drm"):
+    """CPUs next to GPU `local_rank` (its PCIe root's NUMA node), from sysfs alone — no HIP call, so a
+    rank can bind itself before it touches the GPU.  The kfd topology lists the GPUs in HIP's device
+    order (nodes this container may not read belong to other tenants and are skipped); a GPU node names
+    its DRM render node (`drm_render_minor`) and its PCI address (`domain`, `location_id` = bus << 8 |
+    device << 3 | function); `<drm>/renderD<minor>/device/local_cpulist`, else
+    `<pci>/<address>/local_cpulist`, holds the CPUs of that device's NUMA node.
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES renumber the devices: the list is followed when it holds
+    plain indices.  Returns a sorted CPU list, or None when anything is missing (then nothing is bound)."""
+    try:
+        gpus = []
+        for node in sorted(os.listdir(kfd_root), key=lambda x: int(x)):
+            try:
+                with open(os.path.join(kfd_root, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            v = os.environ.get(var)
+            if v:
+                gpus = [gpus[int(x)] for x in v.split(",") if x.strip() != ""]
+        props = gpus[local_rank]
+        cands = []
+        if int(props.get("drm_render_minor", "0")) > 0:
+            cands.append(os.path.join(drm_root, f"renderD{int(props['drm_render_minor'])}", "device", "local_cpulist"))
+        if "location_id" in props:
+            domain, loc = int(props.get("domain", "0")), int(props["location_id"])
+            cands.append(os.path.join(pci_root, f"{domain:04x}:{(loc >> 8) & 0xFF:02x}:{(loc >> 3) & 0x1F:02x}.{loc & 7:x}", "local_cpulist"))
+        for path in cands:
+            try:
+                with open(path) as f:
+                    cpus = _cpulist(f.read())
+                if cpus:
+                    return cpus
+            except OSError:
+                continue
+        return None
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
+def bind_to_gpu_node(local_rank: int, local_world: int = 1, **roots):
+    """Pin this process (and the loader threads it will start) to the CPUs next to its GPU; ranks
+    that share a NUMA node split its CPUs evenly (rank r of the k ranks on that node takes every
+    k-th slice).  Called by a rank BEFORE its first GPU call: pinned buffers are then allocated on
+    the right node and eight ranks' loader threads do not land on one socket.  PFA_NO_AFFINITY=1
+    switches it off.  Returns the CPU list it bound to, or None."""
+    if os.environ.get("PFA_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
+        return None
+    mine = gpu_local_cpus(local_rank, **roots)
+    if not mine:
+        return None
+    allowed = sorted(set(mine) & os.sched_getaffinity(0))
+    if not allowed:
+        return None
+    # the ranks whose GPUs sit on the same CPUs share them out
+    same = [r for r in range(max(local_world, 1)) if gpu_local_cpus(r, **roots) == mine] or [local_rank]
+    k, me = len(same), same.index(local_rank) if local_rank in same else 0
+    share = allowed[me * len(allowed) // k:(me + 1) * len(allowed) // k] or allowed
+    try:
+        os.sched_setaffinity(0, share)
+    except OSError:
+        return None
+    return share
 
 
 # ---------------------------------------------------------------- launcher
@@ -151,6 +257,10 @@ def spawn_ranks(n: int, argv, timeout=None) -> int:
     port = _free_port()
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: RCCL's intra-node transport shares device buffers between the rank
+        # processes through IPC handles; the kernel driver of this pool only implements the dmabuf flavour,
+        # and with the runtime's legacy default hipIpcGetMemHandle fails ("invalid argument") inside
+        # ncclCommInitRank.  The pool's images export it already; a value the user set is kept.
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PFA_RDZV_FILE=os.path.join(rdzv, "rccl_id"),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -278,6 +388,12 @@ class Comm:
         blobs = self.all_gather_bytes(local.view(np.uint8).reshape(-1).tobytes())
         return [np.frombuffer(b, dtype=local.dtype).copy() for b in blobs]
 
+    def gather_bytes(self, blob: bytes, dst=0):
+        """A byte string of any length from every rank, on rank `dst` only (None elsewhere).  The
+        default goes through the all-gather; RcclComm sends to `dst` alone."""
+        blobs = self.all_gather_bytes(blob)
+        return blobs if self.rank == dst else None
+
     def gather_objects(self, obj, dst=0):
         """Small python metadata (names, comment lines) of every rank, on rank `dst`."""
         blobs = self.all_gather_bytes(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
@@ -322,6 +438,22 @@ class RcclComm(Comm):
         recv = np.empty((self.world, len(send)), dtype=np.uint8)
         self._lib.check(self._lib.load().pfa_comm_all_gather(self._lib.ptr(send), self._lib.ptr(recv), len(send)))
         return recv
+
+    def gather_bytes(self, blob: bytes, dst=0):
+        """Variable-size gather to one rank: the sizes travel in a one-word all-gather, the payloads as
+        ncclSend / ncclRecv to `dst` alone (pfa_comm_gatherv) — nobody but the printing rank receives
+        the records, and nothing is padded to the largest rank."""
+        lib = self._lib.load()
+        mine = np.array([len(blob)], dtype=np.uint64)
+        counts = np.ascontiguousarray(self.all_gather_fixed(mine.view(np.uint8)).view(np.uint64).reshape(-1))
+        send = np.frombuffer(blob, dtype=np.uint8) if len(blob) else np.zeros(1, dtype=np.uint8)
+        recv = np.empty(max(int(counts.sum()), 1), dtype=np.uint8) if self.rank == dst else None
+        self._lib.check(lib.pfa_comm_gatherv(self._lib.ptr(np.ascontiguousarray(send)), len(blob), self._lib.ptr(recv),
+                                             self._lib.ptr(counts), int(dst)))
+        if self.rank != dst:
+            return None
+        ends = np.cumsum(counts).tolist()
+        return [recv[e - int(c):e].tobytes() for e, c in zip(ends, counts.tolist())]
 
     def all_gather_plan_results(self, plan) -> np.ndarray:
         """The records of the plan's last run, of every rank, gathered from device memory

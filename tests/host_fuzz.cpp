@@ -65,6 +65,19 @@ static void fuzz_text(const std::string& s) {
   // exact-size heap copy: ASan sees any read past the end
   uint8_t* text = (uint8_t*)malloc(s.size() ? s.size() : 1);
   memcpy(text, s.data(), s.size());
+  {   // the in-place indexer of the streaming ingest, on its own exact-size copy
+    uint8_t* t2 = (uint8_t*)malloc(s.size() ? s.size() : 1);
+    memcpy(t2, s.data(), s.size());
+    std::vector<pfa_fasta_row> rows(s.size() / 2 + 2);
+    const int64_t k = pfa_fasta_index_compact(s.size() ? t2 : nullptr, s.size(), rows.data(), rows.size());
+    for (int64_t i = 0; i < k; ++i) {
+      const pfa_fasta_row& r = rows[(size_t)i];
+      if (r.name_off + r.name_len > s.size() || (r.seq_len && r.seq_off + r.seq_len > s.size())) { fprintf(stderr, "index_compact: record %lld out of bounds\n", (long long)i); abort(); }
+      volatile uint8_t sink = 0;
+      for (uint32_t b = 0; b < r.seq_len; ++b) sink ^= t2[r.seq_off + b];
+    }
+    free(t2);
+  }
   const int64_t n = pfa_fasta_index(s.size() ? text : nullptr, s.size(), nullptr, 0);
   if (n > 0) {
     std::vector<pfa_fasta_rec> recs((size_t)n);

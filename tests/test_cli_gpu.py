@@ -125,24 +125,73 @@ def test_pops_rows(gpu, tmp_path):
 
 
 def test_many_files_small_buffers(gpu, tmp_path, monkeypatch):
-    """Force several ingest batches, deferred files and one file larger than the
-    buffer: rows must still come out once each, in sorted-path order."""
-    import numpy as np
+    """Force many small pinned slots (every slot = one H2D copy, several batches) and one file
+    larger than a slot, which travels in buffers of its own: rows must still come out once each,
+    in sorted-path order, for one loader thread and for many."""
     from oracle import c_oracle
-    monkeypatch.setattr(cli, "BATCH_BYTES", 1 << 20)
-    monkeypatch.setattr(cli, "_pinned_cache", [None, None])
+    monkeypatch.setenv("PFA_INGEST_SLOT_BYTES", str(1 << 20))
     rows = {}
     p = synth.make_params(12, 0.02)
     for i in range(40):
-        L = 30000 if i != 17 else 200000          # file 17 alone exceeds the 1 MiB buffer
+        L = 30000 if i != 17 else 200000          # file 17 alone exceeds the 1 MiB slot
         m = synth.synth_alignment(900, i, L, p)
         (tmp_path / f"f{i:02d}.fa").write_text(synth.to_fasta_text(synth.headers_for(12), m))
         o = c_oracle.scan(m)
         rows[f"f{i:02d}.fa"] = (L, o["S"])
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("PFA_THREADS", threads)
+        rc, out = run_cli(["-d", str(tmp_path), "-s"])
+        lines = out.rstrip("\n").split("\n")
+        assert [ln.split(",")[0] for ln in lines] == sorted(rows)
+        for ln in lines:
+            f = ln.split(",")
+            assert (int(f[1]), int(f[4])) == rows[f[0]]
+
+
+def test_ingest_repacks_any_text_like_the_reference_reader(gpu, tmp_path):
+    """The streaming ingest end to end against the oracle's reader on awkward files: wrapped records,
+    CRLF and lone-CR line ends, lower case, blank lines, trailing blanks, duplicate headers, text before
+    the first header, no final newline, rows of 1..40 sites at every byte offset (the repack kernel reads
+    unaligned runs), IUPAC / gap symbols, and a file with a byte >= 0x80 in a sequence line."""
+    import io
+    import random
+    from oracle import c_oracle, polyfasta_oracle as orc
+    rng = random.Random(23)
+    want = {}
+    for i in range(60):
+        eol = rng.choice(["\n", "\r\n", "\r"])
+        n, L = rng.randint(2, 9), rng.choice([1, 2, 3, 5, 15, 16, 17, 31, 33, 40, 257, 1000])
+        seqs = ["".join(rng.choice("ACGTacgtNn-RY") for _ in range(L)) for _ in range(n)]
+        seqs[1] = seqs[0]
+        text = rng.choice(["", "junk before\n"])
+        for r, sq in enumerate(seqs):
+            w = rng.choice([1000, 60, 7])
+            lines = [sq[k:k + w] + rng.choice(["", " ", "\t"]) for k in range(0, L, w)]
+            if rng.random() < 0.3:
+                lines.insert(rng.randint(0, len(lines)), "")
+            text += f">{'x' * rng.randint(0, 5)}s{r}" + eol + eol.join(lines) + (eol if r + 1 < n or rng.random() < 0.7 else "")
+        if i % 10 == 3:
+            text = f">s0{eol}TTTT{eol}" + text                   # the first s0 is overwritten, its position kept
+        (tmp_path / f"t{i:02d}.fa").write_bytes(text.encode())
+        d = orc.parse_fasta_lines(io.StringIO(text, newline=None))
+        if len({len(v) for v in d.values()}) != 1:
+            want[f"t{i:02d}.fa"] = None                          # PolyFastA.py:135-140
+            continue
+        m = __import__("numpy").array([list(v.encode()) for v in d.values()], dtype="uint8")
+        o = c_oracle.scan(m)
+        want[f"t{i:02d}.fa"] = (L, len(d), o["S"], o["H"])
+    (tmp_path / "t99_bad.fa").write_bytes(b">a\nAC\xc3\xb1T\n>b\nACGTT\n")
     rc, out = run_cli(["-d", str(tmp_path), "-s"])
     lines = out.rstrip("\n").split("\n")
-    assert [ln.split(",")[0] for ln in lines] == sorted(rows)
-    for ln in lines:
+    assert lines[-1] == "# Sequences hold non-ASCII characters (not supported, one byte per base): t99_bad.fa"
+    assert len(lines) - 1 == len(want)
+    for ln, name in zip(lines[:-1], sorted(want)):
+        if want[name] is None:
+            assert ln == f"# Sequences do not have the same length: {name}"
+            continue
         f = ln.split(",")
-        assert (int(f[1]), int(f[4])) == rows[f[0]]
-    monkeypatch.setattr(cli, "_pinned_cache", [None, None])
+        assert f[0] == name
+        L, n, S, H = want[f[0]]
+        assert (int(f[1]), int(f[3]), int(f[4])) == (L, n, S), (ln, want[f[0]])
+        if S:
+            assert abs(float(f[5]) - H / (n * (n - 1)) / L) <= 1e-12 * float(f[5])

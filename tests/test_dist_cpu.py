@@ -178,3 +178,70 @@ def test_cli_gpus_flag_starts_the_ranks_with_the_same_arguments(monkeypatch):
     assert cli.main(["-d", "somedir", "--cds", "--gpus", "8", "-o", "out.csv"]) == 0
     assert seen["n"] == 8 and seen["argv"][1:3] == ["-m", "polyfasta_amd"]
     assert seen["argv"][3:] == ["-d", "somedir", "--cds", "--gpus", "8", "-o", "out.csv"]
+
+
+def test_work_queue_by_count_and_stale_counter_file(tmp_path, monkeypatch):
+    """A count instead of sizes: claims follow the item order (identical on every rank without a stat()
+    per file); a counter file older than the launcher is emptied instead of trusted."""
+    qpath = str(tmp_path / "q")
+    q = dist.WorkQueue(10, 2, qpath)
+    assert q.grain == 1 and [q.claim() for _ in range(3)] == [[0], [1], [2]]
+    q.close()
+    # the same file, as a job that died left it: 3 items claimed, written long before this launcher started
+    os.utime(qpath, (1_000_000, 1_000_000))
+    q2 = dist.WorkQueue(10, 2, qpath)
+    assert q2.claim() == [0]
+    q2.close(unlink=True)
+    assert not os.path.exists(qpath)
+
+
+def test_rank_binds_to_the_cpus_next_to_its_gpu(tmp_path, monkeypatch):
+    """dist.gpu_local_cpus / bind_to_gpu_node from a fake sysfs: kfd nodes (two CPU nodes, four GPUs on two
+    PCIe roots), the PCI address out of domain / location_id, local_cpulist of that address; ranks on the
+    same NUMA node split its CPUs; a missing tree binds nothing."""
+    kfd, pci = tmp_path / "kfd", tmp_path / "pci"
+    gpus = [(0, 0x0500), (0, 0x2600), (1, 0x8500), (1, 0xa600)]
+    for i in range(2):      # CPU-only nodes come first in the kfd topology
+        (kfd / str(i)).mkdir(parents=True)
+        (kfd / str(i) / "properties").write_text("cpu_cores_count 64\nsimd_count 0\n")
+    allowed = sorted(os.sched_getaffinity(0))
+    lists = [allowed[:max(1, len(allowed) // 2)], allowed[len(allowed) // 2:] or allowed]
+    drm = tmp_path / "drm"
+    for g, (domain, loc) in enumerate(gpus):
+        (kfd / str(2 + g)).mkdir()
+        # GPUs 0, 1 are found through their DRM render node, GPUs 2, 3 through their PCI address
+        minor = 128 + 8 * g if g < 2 else 0
+        (kfd / str(2 + g) / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\ndomain {domain}\nlocation_id {loc}\ndrm_render_minor {minor}\n")
+        addr = f"{domain:04x}:{(loc >> 8) & 0xFF:02x}:{(loc >> 3) & 0x1F:02x}.{loc & 7:x}"
+        where = (drm / f"renderD{minor}" / "device") if minor else (pci / addr)
+        where.mkdir(parents=True)
+        cl = lists[g // 2]
+        (where / "local_cpulist").write_text(f"{cl[0]}-{cl[-1]}\n" if cl == list(range(cl[0], cl[-1] + 1)) else ",".join(map(str, cl)) + "\n")
+    (kfd / "9").mkdir()                                    # another tenant's GPU: its properties cannot be read
+    (kfd / "9" / "properties").mkdir()
+    roots = dict(kfd_root=str(kfd), pci_root=str(pci), drm_root=str(drm))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "PFA_NO_AFFINITY"):
+        monkeypatch.delenv(var, raising=False)
+    assert dist.gpu_local_cpus(0, **roots) == lists[0] and dist.gpu_local_cpus(3, **roots) == lists[1]
+    assert dist.gpu_local_cpus(4, **roots) is None
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3,0")
+    assert dist.gpu_local_cpus(0, **roots) == lists[1] and dist.gpu_local_cpus(1, **roots) == lists[0]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    before = os.sched_getaffinity(0)
+    try:
+        got = dist.bind_to_gpu_node(1, 4, **roots)       # GPUs 0 and 1 share node 0: rank 1 takes its second half
+        share = lists[0][len(lists[0]) // 2:] or lists[0]
+        assert got == share and sorted(os.sched_getaffinity(0)) == share
+    finally:
+        os.sched_setaffinity(0, before)
+    assert dist.bind_to_gpu_node(0, 1, kfd_root=str(tmp_path / "nope"), pci_root=str(pci)) is None
+    assert os.sched_getaffinity(0) == before
+    monkeypatch.setenv("PFA_NO_AFFINITY", "1")
+    assert dist.bind_to_gpu_node(0, 4, **roots) is None
+
+
+def test_multi_node_launch_is_refused(monkeypatch):
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert dist.single_node(4) and not dist.single_node(8)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert dist.single_node(8)

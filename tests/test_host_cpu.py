@@ -345,3 +345,119 @@ def test_batch_loader_survives_anything_on_the_path_list(tmp_path):
     with pytest.raises(_lib.PfaError) as e:
         fasta.parse_fasta_bytes(raw)
     assert e.value.code == _lib.PFA_ERR_UNSUPPORTED
+
+
+def test_index_compact_matches_reference_reader():
+    """The single-pass, in-place indexer of the streaming ingest (pfa_fasta_index_compact): record
+    names and — after the upper-casing the card does — sequences equal the oracle's restatement of
+    readfasta on random byte soup, wrapped records, CR / CRLF files and duplicate headers."""
+    import io
+    import random
+    from oracle import polyfasta_oracle as orc
+    lib = _lib.load()
+    rng = random.Random(17)
+    alphabet = [">", "\n", "\r", "\r\n", " ", "A", "c", "-", "\t", "\x1c", "G", "n", ">x", "\n>", "T", "\x0b", "\x0c", ">x\n", "ACGTacgt"]
+
+    def check(text):
+        want = orc.parse_fasta_lines(io.StringIO(text, newline=None))
+        raw = np.frombuffer(text.encode("latin-1"), dtype=np.uint8).copy()
+        rows = np.zeros(len(raw) // 2 + 2, dtype=_lib.FASTA_ROW_DTYPE)
+        n = lib.pfa_fasta_index_compact(_lib.ptr(raw) if len(raw) else None, len(raw), _lib.ptr(rows), len(rows))
+        if want is None:
+            assert n == _lib.PFA_ERR_FORMAT, (repr(text), n)
+            return
+        assert n == len(want), (repr(text), n, want)
+        got = {}
+        for r in rows[:n]:
+            name = raw[int(r["name_off"]):int(r["name_off"]) + int(r["name_len"])].tobytes().decode("latin-1")
+            seq = raw[int(r["seq_off"]):int(r["seq_off"]) + int(r["seq_len"])].tobytes().decode("latin-1").upper()
+            got[name] = seq
+        assert got == want and list(got) == list(want), (repr(text), got, want)
+
+    for _ in range(4000):
+        check("".join(rng.choice(alphabet) for _ in range(rng.randint(0, 60))))
+    # wrapped records with every line ending, blank and blank-padded lines, duplicate names
+    for _ in range(300):
+        eol = rng.choice(["\n", "\r\n", "\r"])
+        recs = []
+        for r in range(rng.randint(1, 6)):
+            seq = "".join(rng.choice("ACGTacgtN-") for _ in range(rng.randint(0, 200)))
+            w = rng.choice([7, 60, 1000])
+            lines = [seq[i:i + w] + rng.choice(["", " ", "\t "]) for i in range(0, len(seq), w)]
+            if rng.random() < 0.3:
+                lines.insert(rng.randint(0, len(lines)), rng.choice(["", "  "]))
+            recs.append(f">s{rng.randint(0, 4)} x" + eol + eol.join(lines) + (eol if rng.random() < 0.9 or r < 5 else ""))
+        check("".join(recs))
+
+
+def test_row_blocks_format_natively_like_the_row_path(tmp_path):
+    """A RowBlock written in one native call (pfa_format_rows_indexed: names and population keys looked
+    up by index) equals the same rows through the per-row path, for non-coding and coding rows, with and
+    without keys, --jc, through stdout, a silent --out file and the progress-chatter mode; blocks that
+    travel between ranks (to_bytes / from_bytes, concat, sorted) keep their rows."""
+    import io
+    from contextlib import redirect_stdout
+    from types import SimpleNamespace
+    from polyfasta_amd.ingest import NameTable
+    rng = np.random.default_rng(5)
+    n_files = 700
+    paths = sorted(f"some/dir/aln{i:04d}.fa" if i % 9 else f"d/séq{i:04d}.fa" for i in range(n_files))
+    keys = ["pop1", "p2", "longer_population_name"]
+    for coding in (False, True):
+        for with_keys in (False, True):
+            table = NameTable.from_paths(paths, keys if with_keys else [])
+            meta, recs, syns = [], [], []
+            for f in range(n_files):
+                for k in (range(len(keys)) if with_keys else [_lib.PFA_NO_KEY]):
+                    if with_keys and rng.random() < 0.2:
+                        continue
+                    n = int(rng.choice([2, 3, 4, 20, 50, 200]))
+                    L = int(rng.choice([300, 9000, 10000]))
+                    seg = 0 if rng.random() < 0.1 else int(rng.integers(1, 300))
+                    s_s = int(rng.integers(0, seg + 1))
+                    s_n = seg - s_s
+                    h_s, h_n = int(rng.integers(1, max(2, n * n // 2))) * s_s, int(rng.integers(1, max(2, n * n // 2))) * s_n
+                    recs.append((h_s + h_n, h_s, h_n, seg, 0, s_s, s_n, int(rng.integers(0, 9)), int(rng.integers(0, 5)), 0, 0))
+                    syn = np.zeros(_lib.PFA_SYN_BINS, dtype=np.uint32)
+                    syn[1], syn[2], syn[3] = rng.integers(1, L // 3), rng.integers(0, 90), rng.integers(0, 9)
+                    syns.append(syn)
+                    meta.append((f, k, n, L))
+            blk = cli.RowBlock(np.array(meta, dtype=cli.META_DTYPE), np.array(recs, dtype=_lib.RESULT_DTYPE),
+                               np.stack(syns) if coding else None)
+            kstr = keys if with_keys else []
+            for jc in (False, True):
+                args = SimpleNamespace(cds=coding, jc=jc, sfs=False)
+                want = "".join((cli.format_cds_row(e[2], e[3], e[4], e[5], e[6], e[7], jc) if coding
+                                else cli.format_plain_row(e[2], e[3], e[4], e[5], e[6], jc)) + "\n"
+                               for e in cli.block_events(blk, paths, kstr))
+                same = cli.format_block_native(blk, table, coding, jc) == want
+                assert same
+                buf = io.StringIO()
+                with redirect_stdout(buf):
+                    cli.emit_block(blk, cli.Sink("", True), args, table, paths, kstr)
+                same = buf.getvalue() == want
+                assert same
+            # --out without --silent: rows in the file, the reference's chatter on stdout
+            args = SimpleNamespace(cds=coding, jc=False, sfs=False)
+            out_a, out_b = tmp_path / f"a{coding}{with_keys}.csv", tmp_path / f"b{coding}{with_keys}.csv"
+            bufs = []
+            for out, fn in ((out_a, lambda sk: cli.emit_block(blk, sk, args, table, paths, kstr)),
+                            (out_b, lambda sk: cli.emit(cli.block_events(blk, paths, kstr), sk, coding, False))):
+                buf = io.StringIO()
+                with redirect_stdout(buf):
+                    sk = cli.Sink(str(out), False)
+                    fn(sk)
+                    sk.flush()
+                bufs.append(buf.getvalue())
+            same = out_a.read_text() == out_b.read_text() and bufs[0].replace(str(out_a), "F") == bufs[1].replace(str(out_b), "F")
+            assert same and "Writting to" in bufs[0][:40]          # (a bool: pytest would diff megabytes of text)
+            # special lines force the event path, in file order; halves gathered out of order come back sorted
+            blk.specials = [(3, 0, "comment", "# CDS sequence length is not a multiple of 3: x"), (5, 2, "comment", "# Pop p2 string was not found in fasta headers.")]
+            ev = cli.block_events(blk, paths, kstr)
+            assert [e[0] for e in ev] == sorted(e[0] for e in ev)
+            half = len(blk.meta) // 2
+            parts = [cli.RowBlock(blk.meta[half:], blk.rec[half:], None if blk.syn is None else blk.syn[half:]),
+                     cli.RowBlock(blk.meta[:half], blk.rec[:half], None if blk.syn is None else blk.syn[:half], specials=blk.specials)]
+            back = cli.RowBlock.concat([cli.RowBlock.from_bytes(x.to_bytes()) for x in parts], coding).sorted()
+            assert (back.meta == blk.meta).all() and (back.rec == blk.rec).all() and back.specials == blk.specials
+            assert coding is False or (back.syn == blk.syn).all()
