@@ -53,8 +53,11 @@ def parse(argv=None):
                     help="config 3 shape: every matrix holds rows*pops sequences, scanned as `pops` interleaved row subsets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline measurement only (profiling runs)")
+    ap.add_argument("--legs", default="small_launches,workloads,end_to_end,cold_start",
+                    help="which extra legs of the default run to take (comma-separated)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--e2e-files", type=int, default=8192, help="FASTA files of the plain end-to-end leg (the coding / --pops legs use half as many)")
+    ap.add_argument("--e2e-files-per-rank", type=int, default=4096, help="files per rank of the N > 1 end-to-end leg (weak scaling)")
     ap.add_argument("--e2e-reps", type=int, default=5, help="warm runs per end-to-end mode (best and median are reported)")
     return ap.parse_args(argv)
 
@@ -110,7 +113,8 @@ class Workload:
         avg = float(kms.mean())
         ach = self.alg_bytes / (avg * 1e-3) / 1e9
         return {"workload": self.label(), "kernel": self.plan.description, "launches_per_run": self.plan.n_launches,
-                "kernel_ms_avg": avg, "kernel_ms_min": float(kms.min()), "algorithmic_bytes_per_launch": self.alg_bytes,
+                "kernel_ms_avg": avg, "kernel_ms_min": float(kms.min()), "kernel_ms_p50": float(np.percentile(kms, 50)),
+                "kernel_ms_p95": float(np.percentile(kms, 95)), "timed_runs": int(len(kms)), "algorithmic_bytes_per_launch": self.alg_bytes,
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "frac_of_measured_copy_6290": ach / 6290.0,
                 # scan units (alignment x population = CSV rows) per second of kernel time
@@ -127,9 +131,18 @@ def extra_workloads(args):
     for key, kw in (("C4_coding_50x9000", dict(rows=50, sites=9000, batch=32768, coding=True)),
                     ("C3_pops_2x100x100000", dict(rows=100, sites=100000, batch=128, pops=2)),
                     ("N200_plain_200x100000", dict(rows=200, sites=100000, batch=128)),
-                    ("N200_coding_200x9000", dict(rows=200, sites=9000, batch=8192, coding=True))):
-        w = Workload(theta=args.theta, stride_align=args.stride_align, **kw)
-        out[key] = w.measure(steps=24, warmup=6)
+                    ("N200_coding_200x9000", dict(rows=200, sites=9000, batch=8192, coding=True)),
+                    # units with many rows: the row-chunked kernel (and its wide form above 2 048 coding rows)
+                    ("N1000_coding_1000x9000", dict(rows=1000, sites=9000, batch=1024, coding=True)),
+                    ("N5000_coding_5000x9000", dict(rows=5000, sites=9000, batch=256, coding=True)),
+                    # BASELINE configs[4] at its full size on ONE GPU: 100 000 alignments = 50 GB of bases resident in HBM
+                    ("C5_batch_100000x50x10000", dict(rows=50, sites=10000, batch=100000))):
+        try:
+            w = Workload(theta=args.theta, stride_align=args.stride_align, **kw)
+        except Exception as e:                  # noqa: BLE001  (e.g. not enough free HBM for the 50 GB batch)
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+            continue
+        out[key] = w.measure(steps=24 if kw["batch"] < 100000 else 10, warmup=6 if kw["batch"] < 100000 else 2)
         o = w.plan.fetch()
         out[key]["check"] = {"mean_seg_sites": float(o.results["seg_sites"].mean()), "sum_H": int(o.results["H"].sum())}
         w.close()
@@ -278,6 +291,128 @@ def end_to_end(args):
         shutil.rmtree(root, ignore_errors=True)
         if os.path.exists(out):
             os.unlink(out)
+
+
+def end_to_end_ranks(args, comm, rank, world):
+    """The thing north_star shards, measured: `--dir` through the shared work queue on `world` ranks.  Every rank
+    writes its share of one tmpfs directory (N = 50 x 10 kb files, `--e2e-files-per-rank` per rank: weak scaling),
+    then all ranks run `python -m polyfasta_amd -d DIR -o out.csv -s` in-process on this bench's communicator: each drains
+    dist.WorkQueue, the row blocks travel to rank 0 once, rank 0 orders and writes them.  The timed region is the whole
+    cli.main() of the slowest rank (the gather and rank 0's emit are inside); rows are checked against the C oracle."""
+    import io
+    import shutil
+    import tempfile
+    from contextlib import redirect_stdout
+    from oracle import c_oracle
+    from polyfasta_amd import _lib, cli, scan, synth
+    lib = _lib.load()
+    N, L = 50, 10000
+    per = args.e2e_files_per_rank
+    M = per * world
+    root = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir(), f"pfa_e2e_ranks_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+    out = os.path.join(tempfile.gettempdir(), f"pfa_e2e_ranks_out_{os.getppid()}.csv")
+    p = synth.make_params(N, args.theta)
+    stride = scan.row_stride_for(L, 128)
+    try:
+        if rank == 0:
+            shutil.rmtree(root, ignore_errors=True)
+            os.makedirs(root)
+        comm.barrier()
+        sp = _lib.SynthParamsC(seed=7, first_aln=rank * per, n_aln=per, n_rows=N, n_sites=L, row_stride=stride, seg_thresh=p.seg_thresh,
+                               tri_thresh=p.tri_thresh, n_units=len(p.units), coding=0)
+        bases = np.zeros(per * N * stride, dtype=np.uint8)
+        _lib.check(lib.pfa_synth_fill_host(_lib.ptr(bases), ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(p.cdf)),
+                                           _lib.ptr(np.ascontiguousarray(p.units))))
+        hdr = [f">indiv{i + 1}\n".encode() for i in range(N)]
+        for k in range(per):
+            mat = bases[k * N * stride:(k + 1) * N * stride].reshape(N, stride)[:, :L]
+            with open(os.path.join(root, f"aln{rank * per + k:07d}.fa"), "wb") as fh:
+                fh.write(b"".join(h + mat[i].tobytes() + b"\n" for i, h in enumerate(hdr)))
+        comm.barrier()
+        times = []
+        for rep in range(1 + args.e2e_reps):
+            if rank == 0 and os.path.exists(out):
+                os.unlink(out)
+            comm.barrier()
+            t0 = time.perf_counter()
+            with redirect_stdout(io.StringIO()):
+                rc = cli.main(["-d", root, "-o", out, "-s"], comm=comm, close_comm=False)
+            times.append(comm.max_float(time.perf_counter() - t0))
+            comm.barrier()        # rank 0 has removed the queue file: the next run makes its own
+        if rank != 0:
+            return None
+        rows = open(out).read().splitlines()
+        ok = rc == 0 and len(rows) == M and [r.split(",")[0] for r in rows] == [f"aln{m:07d}.fa" for m in range(M)]
+        s_cpu, h_cpu = c_oracle.scan_many(bases, min(48, per), N, L, stride)      # rank 0 wrote files 0 .. per-1
+        for i in range(min(48, per)):
+            f = rows[i].split(",")
+            pi = int(h_cpu[i]) / (N * (N - 1)) / L
+            ok = ok and int(f[4]) == int(s_cpu[i]) and abs(float(f[5]) - pi) <= 1e-9 * pi
+        warm = sorted(times[1:])
+        return {"files": M, "files_per_rank": per, "ranks": world, "alignments_per_s": M / warm[0], "seconds": warm[0],
+                "median_alignments_per_s": M / warm[len(warm) // 2], "first_run_s": times[0], "text_GBps": M * N * (L + 10) / warm[0] / 1e9,
+                "rows_ok": bool(ok), "scaling": "weak",
+                "command": "python -m polyfasta_amd -d DIR -o out.csv -s on every rank (in-process, shared work queue, one gather to rank 0)"}
+    finally:
+        comm.barrier()
+        if rank == 0:
+            shutil.rmtree(root, ignore_errors=True)
+            if os.path.exists(out):
+                os.unlink(out)
+
+
+def cold_start(args):
+    """BASELINE configs[1], [2], [3] as a user runs them: ONE file, ONE fresh process (`python -m polyfasta_amd -f FILE ...`
+    started with subprocess — never a re-exec of this process), wall time from spawn to exit, median of 5, split into phases
+    the child reports (PFA_TRACE_STARTUP).  The reference's whole-process figure on the survey container: 0.15-0.17 s for
+    config 2 (0.09-0.13 s of it interpreter + numpy import); it cannot be run on this box."""
+    import shutil
+    import subprocess
+    import tempfile
+    from polyfasta_amd import synth
+    root = tempfile.mkdtemp(prefix="pfa_cold_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    rep = {"command": "python -m polyfasta_amd -f FILE [flags] in a fresh process (subprocess), page-cached file, stdout to a pipe",
+           "reference_whole_process_s": "0.15-0.17 (config 2, survey container, BASELINE.md §2)"}
+    try:
+        cases = (("config2_50x10000", 50, 10000, False, 0, []),
+                 ("config3_200x100000_pops_jc", 200, 100000, False, 2, ["-p", "pop1,pop2", "--jc"]),
+                 ("config4_50x9000_cds", 50, 9000, True, 0, ["--cds"]))
+        for name, n, L, coding, pops, flags in cases:
+            p = synth.make_params(n, args.theta)
+            m = synth.synth_alignment(5, 0, L, p, coding=coding)
+            path = os.path.join(root, name + ".fa")
+            with open(path, "wb") as fh:
+                fh.write(b"".join(f">{h}\n".encode() + m[i].tobytes() + b"\n" for i, h in enumerate(synth.headers_for(n, pops))))
+            walls, phases, rows = [], [], None
+            for _ in range(6):
+                env = dict(os.environ, PFA_TRACE_STARTUP="1")
+                t0w, t0 = time.time(), time.perf_counter()
+                pr = subprocess.run([sys.executable, "-m", "polyfasta_amd", "-f", path] + flags, capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+                wall = time.perf_counter() - t0
+                if pr.returncode != 0:
+                    rep[name] = {"error": pr.stderr[-500:]}
+                    break
+                walls.append(wall)
+                rows = pr.stdout.strip().split("\n")
+                marks = [ln for ln in pr.stderr.splitlines() if ln.startswith("PFA_STARTUP ")]
+                if marks:
+                    mk = json.loads(marks[-1][len("PFA_STARTUP "):])
+                    prev, d = t0w, {}
+                    for ph, t in mk:
+                        d[ph] = t - prev
+                        prev = t
+                    d["exit (interpreter teardown, pfa_shutdown)"] = (t0w + wall) - prev
+                    phases.append(d)
+            if name in rep:
+                continue
+            order = np.argsort(walls[1:]) + 1            # the first run pages the libraries in: reported apart
+            med = int(order[len(order) // 2])
+            rep[name] = {"wall_s_median_of_5": walls[med], "wall_s_min": float(min(walls[1:])), "wall_s_first_run": walls[0],
+                         "phases_s_of_the_median_run": phases[med] if len(phases) == len(walls) else None,
+                         "rows": len(rows) - 1, "flags": " ".join(flags)}
+        return rep
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def cpu_baseline(args, hw):
@@ -433,6 +568,13 @@ def main():
     if comm is not None:
         dt = comm.max_float(dt)
 
+    e2e_ranks = None
+    if world > 1 and comm is not None and not args.no_extras and "end_to_end" in args.legs.split(","):
+        try:
+            e2e_ranks = end_to_end_ranks(args, comm, rank, world)
+        except Exception as e:              # noqa: BLE001   (every rank takes the same path: the barriers inside stay matched)
+            e2e_ranks = {"error": f"{type(e).__name__}: {e}"}
+
     kms = plan.kernel_ms(args.steps)
     k_avg_ms = float(kms.mean()) if len(kms) else float("nan")
     achieved = hw.alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
@@ -464,13 +606,22 @@ def main():
                          # best plain streaming read measured on this pool (tools/ubench/read_stream.hip)
                          "frac_of_measured_read_6860": achieved / 6860.0},
             "timing_ms": {"enqueue": t_enq * 1e3, "until_kernels_done": t_run * 1e3, "fetch": t_fetch * 1e3,
-                          "kernel_ms_min": float(kms.min()), "kernel_ms_max": float(kms.max())},
+                          "kernel_ms_min": float(kms.min()), "kernel_ms_max": float(kms.max()),
+                          "kernel_ms_p50": float(np.percentile(kms, 50)), "kernel_ms_p95": float(np.percentile(kms, 95)),
+                          "kernel_runs_timed": int(len(kms))},
             "check": {"mean_seg_sites": float(res["seg_sites"].mean()),
                       "sum_H": int(res["H"].sum()),
                       "gathered_records": None if gathered is None else int(gathered.size),
                       "gathered_rank0_equals_fetch": None if gathered is None else bool((gathered[0] == res).all())},
         }
         line["roofline"]["traffic"], line["roofline"]["traffic_source"] = measured_traffic(line["config"])
+        if os.environ.get("PFA_ALLOW_SHARED_GPU") or os.environ.get("PFA_COMM_FACTORY"):
+            # rehearsal switches (tests): ranks may share one device and talk through an injected communicator —
+            # such a line is not a multi-GPU measurement, and says so
+            line["rehearsal"] = {"shared_gpu": bool(os.environ.get("PFA_ALLOW_SHARED_GPU")), "comm": type(comm).__name__,
+                                 "note": "n_gpus counts ranks, not devices: not a scaling measurement"}
+        if e2e_ranks is not None:
+            line["end_to_end"] = e2e_ranks
         extras = world == 1 and comm is None and not args.no_extras and default_shape
         if extras and not args.no_cpu_baseline:
             try:
@@ -488,11 +639,17 @@ def main():
                     return fn(*a)
                 except Exception as e:          # noqa: BLE001
                     return {"error": f"{type(e).__name__}: {e}"}
-            sl = leg(small_launches, hw, args)
-            line.update(sl if "error" not in sl else {"single_alignment": sl})
+            legs = set(args.legs.split(","))
+            if "small_launches" in legs:
+                sl = leg(small_launches, hw, args)
+                line.update(sl if "error" not in sl else {"single_alignment": sl})
             hw.close()
-            line["workloads"] = leg(extra_workloads, args)
-            line["end_to_end"] = leg(end_to_end, args)
+            if "workloads" in legs:
+                line["workloads"] = leg(extra_workloads, args)
+            if "end_to_end" in legs:
+                line["end_to_end"] = leg(end_to_end, args)
+            if "cold_start" in legs:
+                line["cold_start"] = leg(cold_start, args)
         else:
             hw.close()
         print(json.dumps(line), flush=True)

@@ -119,6 +119,10 @@ uint32_t pfa_var_words_per_tile(uint32_t max_rows, uint32_t cds);
 int pfa_abi_version(void);
 int pfa_device_count(void);
 int pfa_init(int device);
+/* start bringing the HIP runtime up for `device` on a thread of the library's own and return at
+ * once (a command line calls this before it loads its own modules; ~0.1 s of hipInit then runs
+ * under them); pfa_init() waits for it.  Optional. */
+void pfa_prewarm(int device);
 int pfa_device_index(void); /* the device pfa_init() bound, or -1 */
 void pfa_shutdown(void);
 const char* pfa_last_error(void);

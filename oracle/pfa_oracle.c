@@ -82,7 +82,7 @@ int pfa_oracle_scan(const uint8_t* mat, uint32_t n_rows, uint32_t n_sites, uint6
   if (sfs) memset(sfs, 0, (size_t)nbins * sizeof(uint32_t));
   if (labels_out) memset(labels_out, 0, n_sites);
   const uint64_t nn = (uint64_t)n_rows * n_rows;
-  uint32_t hcod[3] = {0, 0, 0};
+  uint64_t hcod[3] = {0, 0, 0};     /* per-site H leaves 32 bits above ~92 000 rows */
 
   for (uint32_t p = 0; p < n_sites; ++p) {
     /* getvarsites PolyFastA.py:255-260 + nucleotide_diversity :485-492 + getsfs :274-282 */
@@ -96,9 +96,9 @@ int pfa_oracle_scan(const uint8_t* mat, uint32_t n_rows, uint32_t n_sites, uint6
     int distinct = 0;
     for (int c = 0; c < 256; ++c)
       if (cnt[c]) { ++distinct; sumsq += (uint64_t)cnt[c] * cnt[c]; }
-    uint32_t hs = 0;
+    uint64_t hs = 0;
     if (distinct > 1) {
-      hs = (uint32_t)(nn - sumsq);
+      hs = nn - sumsq;
       out->S += 1;
       out->H += hs;
       uint32_t a[4] = {cnt['A'], cnt['C'], cnt['G'], cnt['T']};
@@ -108,7 +108,7 @@ int pfa_oracle_scan(const uint8_t* mat, uint32_t n_rows, uint32_t n_sites, uint6
       if (a[1] == 0) out->sfs_bad += 1; /* fewer than two A/C/G/T alleles: IndexError in the reference */
       else if (sfs) sfs[a[1] - 1] += 1;
     }
-    if (h_site_out) h_site_out[p] = hs;
+    if (h_site_out) h_site_out[p] = hs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)hs;   /* (saturates: callers use it as a variable-site mask below 65 536 rows) */
     if (!cds) continue;
 
     /* getvarCDSsites PolyFastA.py:284-315 on the codon column ending here */

@@ -97,6 +97,7 @@ _PROTOTYPES = {
     "pfa_abi_version": (ctypes.c_int, []),
     "pfa_device_count": (ctypes.c_int, []),
     "pfa_init": (ctypes.c_int, [ctypes.c_int]),
+    "pfa_prewarm": (None, [ctypes.c_int]),
     "pfa_device_index": (ctypes.c_int, []),
     "pfa_shutdown": (None, []),
     "pfa_last_error": (ctypes.c_char_p, []),

@@ -35,8 +35,20 @@ _E_OF = {"A": 0, "C": 1, "T": 2, "G": 3}   # device codon encoding: (ascii >> 1)
 
 
 class VarSites(list):
-    """List of variable-site columns + the device's integer summary of them."""
-    summary = None   # dict(N, S, H, sfs, sfs_bad, n_mono)
+    """List of variable-site columns + the device's integer summary of them.  The summary carries a
+    fingerprint of the columns it was computed from (`_fingerprint`): a caller that edits the list or
+    a column in place gets a fresh scan, as the reference's pure functions would give it
+    (PolyFastA.py:485-520 recompute from `var` on every call)."""
+    summary = None   # dict(N, S, H, sfs, sfs_bad, n_mono, fp)
+
+
+def _fingerprint(var):
+    """(columns, CRC of every character) of a list of columns; None when an entry is not a string"""
+    import zlib
+    try:
+        return len(var), zlib.crc32("\x01".join(map("\x00".join, var)).encode("utf-8", "surrogatepass"))
+    except TypeError:
+        return None
 
 
 def _columns_to_matrix(var) -> np.ndarray:
@@ -59,14 +71,14 @@ def _columns_to_matrix(var) -> np.ndarray:
 def _summary_of(var):
     """Integer summary of a list of columns, scanning on the GPU if needed."""
     s = getattr(var, "summary", None)
-    if s is not None and s["S_listed"] == len(var):
+    if s is not None and s.get("fp") is not None and s["fp"] == _fingerprint(var):
         return s
     m = _columns_to_matrix(var)
     out = scan_matrix(m)
     r = out.results[0]
     return {"N": m.shape[0], "S_listed": len(var), "S": int(r["seg_sites"]), "H": int(r["H"]),
             "sfs": out.sfs(0).astype(np.int64), "sfs_bad": int(r["sfs_bad"]),
-            "n_mono": len(var) - int(r["seg_sites"])}
+            "n_mono": len(var) - int(r["seg_sites"]), "fp": _fingerprint(var)}
 
 
 def all_same(items):
@@ -99,6 +111,7 @@ def getvarsites(d, seqlen):
     r = out.results[0]
     var.summary = {"N": len(names), "S_listed": len(pos), "S": int(r["seg_sites"]), "H": int(r["H"]),
                    "sfs": out.sfs(0).astype(np.int64), "sfs_bad": int(r["sfs_bad"]), "n_mono": 0}
+    var.summary["fp"] = _fingerprint(var)
     return pos, var
 
 

@@ -525,6 +525,7 @@ def emit_block(blk, sink, args, table, paths, keys):
     emit(block_events(blk, paths, keys), sink, args.cds, args.jc, args.sfs)
 
 
+startup_marks = []  # (phase that ENDS here, wall clock): __main__ and main() append; printed when PFA_TRACE_STARTUP is set
 last_stats = {}     # what the last run_files() measured (bench.py `end_to_end`: the stage breakdown)
 
 
@@ -599,13 +600,15 @@ def run_files(paths, args, sink, rank, world, comm, wq, keys):
             print("PFA_TRACE close", round(time.perf_counter() - t9, 5), file=sys.stderr)
 
 
-def main(argv=None, comm=None):
-    """`comm`: a dist.Comm to use instead of RCCL (tests); with WORLD_SIZE > 1 and no `comm`
-    the ranks talk through dist.RcclComm."""
+def main(argv=None, comm=None, close_comm=True):
+    """`comm`: a dist.Comm to use instead of making one (tests inject gloo; bench.py lends its own and
+    keeps it: `close_comm=False`); with WORLD_SIZE > 1 and no `comm` the ranks talk through dist.RcclComm."""
     import time
     t_main = time.perf_counter()
+    mark = (lambda name: startup_marks.append((name, time.time()))) if os.environ.get("PFA_TRACE_STARTUP") else (lambda name: None)
     parser = build_parser()
     args = parser.parse_args(argv)
+    mark("argparse")
 
     if args.file == "" and args.dir == "." and not args.pipe:                      # PolyFastA.py:84-88
         print("Both --file/-f and --dir/-d were not found.")
@@ -639,7 +642,10 @@ def main(argv=None, comm=None):
     # sit on the socket the card hangs off (H2D from the other socket ran 33 instead of 54 GB/s here)
     dist.bind_to_gpu_node(dist.env_world()[1], int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     try:                                   # the scan runs on the GPU or not at all: say so before any output
+        _lib.load()
+        mark("dlopen libpfa_hip.so (+ libamdhip64)")
         _lib.init()                        # GPU LOCAL_RANK
+        mark("pfa_init (hipInit, device, stream)")
         if comm is None and (world > 1 or os.environ.get("PFA_FORCE_DIST")):   # PFA_FORCE_DIST: one-rank RCCL rehearsal
             comm = dist.RcclComm()
     except (_lib.PfaError, _lib.PfaLibraryError, TimeoutError) as e:
@@ -670,10 +676,14 @@ def main(argv=None, comm=None):
         finally:
             if wq is not None:
                 wq.close(unlink=rank == 0)       # every rank is past its last claim: the barrier above
+    mark("files -> rows (ingest, first kernel launches, fetch, print)")
     if rank == 0 and len(args.out) != 0 and not args.silent:                       # :141-142
         print("")
-    if comm is not None:
+    if comm is not None and close_comm:
         comm.close()
+    if os.environ.get("PFA_TRACE_STARTUP"):
+        import json
+        print("PFA_STARTUP " + json.dumps(startup_marks), file=sys.stderr)
     return 0
 
 

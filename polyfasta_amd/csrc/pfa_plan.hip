@@ -6,12 +6,14 @@
 // in a batch of 50-row ones run the row-chunked kernel on their own, the rest keeps the fast
 // shape and its occupancy.
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -64,8 +66,10 @@ __global__ void __launch_bounds__(256) slab_to_host_kernel(uint4* __restrict__ s
 
 // The same for a plan with output replicas (ScanArgs::rep_mask): the replicas are summed on the way
 // — 64-bit words of the records section that hold H, H_S, H_N (words 0-2 of the 7 of a record) as
-// 64-bit integers, everything else as pairs of 32-bit counters — and cleared.  dst == src sums in place.
-__global__ void __launch_bounds__(256) sum_replicas_kernel(unsigned long long* __restrict__ src, unsigned long long* dst, size_t n64,
+// 64-bit integers, everything else as pairs of 32-bit counters — and cleared.  dst == src sums in place
+// (pfa_plan_results_dev): neither pointer is `__restrict__`, so the store of the sum stays behind the
+// clearing store to the same word.
+__global__ void __launch_bounds__(256) sum_replicas_kernel(unsigned long long* src, unsigned long long* dst, size_t n64,
                                                            uint32_t replicas, size_t stride64, size_t n_rec_words,
                                                            volatile uint32_t* flag, uint32_t ticket) {
   for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < n64; w += (size_t)gridDim.x * blockDim.x) {
@@ -218,7 +222,23 @@ int pfa_device_count(void) {
   return n;
 }
 
+// hipInit on a thread of its own, started by the command line before it imports its modules
+static std::thread g_prewarm;
+
+void pfa_prewarm(int device) {
+  if (pfa::ctx().ready || g_prewarm.joinable()) return;
+  try {
+    g_prewarm = std::thread([device]() {
+      int n = 0;
+      if (hipGetDeviceCount(&n) == hipSuccess && device >= 0 && device < n && hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
+      (void)hipGetLastError();
+    });
+  } catch (...) {
+  }
+}
+
 int pfa_init(int device) {
+  if (g_prewarm.joinable()) g_prewarm.join();
   pfa::Context& c = pfa::ctx();
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -252,6 +272,7 @@ int pfa_init(int device) {
 }
 
 void pfa_shutdown(void) {
+  if (g_prewarm.joinable()) g_prewarm.join();
   pfa::Context& c = pfa::ctx();
   if (!c.ready) return;
   (void)hipStreamSynchronize(c.stream);
@@ -766,8 +787,13 @@ int pfa_plan_fetch(pfa_plan* p, pfa_result* results, uint32_t* sfs, uint32_t* sy
       PFA_HIP(hipGetLastError());
       bool seen = false;
       if (d_flag != nullptr) {
+        // poll the flag word (acquire: the slab reads below stay behind it) for at most 2 ms, then fall back
         p->fetch_ticket += 1u;
-        for (uint32_t spin = 0; spin < 2000000u && !seen; ++spin) seen = *h_flag == p->fetch_ticket;   // ~ a few ms at most
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        for (uint32_t spin = 0; !seen; ++spin) {
+          seen = __atomic_load_n(const_cast<const uint32_t*>(h_flag), __ATOMIC_ACQUIRE) == p->fetch_ticket;
+          if (!seen && (spin & 1023u) == 1023u && std::chrono::steady_clock::now() > t_end) break;
+        }
       }
       if (!seen) PFA_HIP(hipStreamSynchronize(st));
       p->host_valid = true;

@@ -163,6 +163,37 @@ def test_output_replicas_sum_to_the_oracle(gpu, monkeypatch, replicas):
     dev.free()
 
 
+@pytest.mark.parametrize("replicas", [4, 32])
+def test_replicas_summed_in_place_for_the_device_side_gather(gpu, monkeypatch, replicas):
+    """pfa_plan_results_dev() sums the output replicas IN PLACE (dst == src in sum_replicas_kernel) for the
+    RCCL gather that reads the records from device memory: the summed records equal what fetch() returns
+    for the same run, and the oracle (the aliasing path had no test)."""
+    import ctypes
+    monkeypatch.setenv("PFA_REPLICAS", str(replicas))
+    p = synth.make_params(50, 0.01)
+    b = scan.Batch(stride_align=128)
+    mats = [synth.synth_alignment(5, k, 30000, p, coding=bool(k & 1)) for k in range(3)]
+    for k, m in enumerate(mats):
+        b.add_unit(b.add_matrix(m), cds=bool(k & 1))
+    bases, table = b.pack()
+    dev = scan.DeviceBuffer(len(bases))
+    dev.upload(bases)
+    plan = scan.Plan(table)
+    assert f"{replicas} output replicas" in plan.description
+    for _ in range(2):
+        plan.run(dev)
+        ptr, nbytes = plan.results_dev()
+        got = np.empty(nbytes, dtype=np.uint8)
+        _lib.check(_lib.load().pfa_download(_lib.ptr(got), ctypes.c_void_p(ptr), nbytes))
+        got = got.view(_lib.RESULT_DTYPE)
+        out = plan.fetch()
+        assert (got == out.results).all()
+        for k, m in enumerate(mats):
+            _check(out, k, m, cds=bool(k & 1))
+    plan.close()
+    dev.free()
+
+
 def test_mixed_batch_costs_the_sum_of_its_parts(gpu):
     """4 000 x (50 x 10 kb) plus 16 x (1 000 x 10 kb) in ONE plan: the 50-row units keep their kernel and
     occupancy (round 1 moved the whole plan onto the row-chunked kernel), so the mixed plan takes about

@@ -181,6 +181,65 @@ def test_row_limit(gpu):
     assert e.value.code == -5
 
 
+def _many_row_matrix(rng, n, L, alphabet):
+    """every site: 1-5 alleles at random frequencies (so that second-largest counts land far above the 256
+    SFS bins the row-chunked kernel keeps in LDS), a few sites with rare third / fourth alleles"""
+    m = np.empty((n, L), dtype=np.uint8)
+    syms = np.frombuffer(alphabet.encode(), dtype=np.uint8)
+    for s in range(L):
+        k = int(rng.integers(1, 6))
+        al = rng.choice(syms, size=k, replace=False)
+        w = rng.random(k) ** 3 + 1e-4
+        m[:, s] = rng.choice(al, size=n, p=w / w.sum())
+    return m
+
+
+@pytest.mark.parametrize("cds", [False, True])
+def test_units_beyond_65536_rows_match_the_oracle(gpu, cds):
+    """What the ABI advertises (PFA_MAX_ROWS = 2^20; the reference has no limit, PolyFastA.py:252-315) against
+    the oracle where N^2 and c^2 leave 32 bits: a 70 000-row unit with 3+ alleles per site, gaps, N and IUPAC
+    bytes — 64-bit H on the device, SFS bins above the 256 kept in LDS, the 56-bit entries of the coding pass."""
+    rng = np.random.default_rng(77 + cds)
+    n, L = 70000, 66 if cds else 64
+    m = _many_row_matrix(rng, n, L, "ACGT" * 3 + "N-RY")
+    m[:, 5] = ord("A")                       # a monomorphic site, a two-allele site with one rare row
+    m[:, 6] = ord("C")
+    m[123, 6] = ord("T")
+    out = scan.scan_matrix(m, cds=cds)
+    o = c_oracle.scan(m, cds=cds)
+    r = out.results[0]
+    assert (int(r["seg_sites"]), int(r["H"]), int(r["sfs_bad"])) == (o["S"], o["H"], o["sfs_bad"])
+    assert int(r["H"]) > 2 ** 32 and out.sfs(0).tolist() == o["sfs"].tolist()
+    assert int(np.flatnonzero(out.sfs(0)).max()) > 256
+    if cds:
+        assert (int(r["seg_S"]), int(r["seg_N"]), int(r["H_S"]), int(r["H_N"]), int(r["nstops"]), int(r["missing_cols"])) == \
+               (o["seg_S"], o["seg_N"], o["H_S"], o["H_N"], o["nstops"], o["missing_cols"])
+    # a row subset of it (--pops on a huge alignment)
+    rows = np.arange(0, n, 1, dtype=np.uint32)[rng.random(n) < 0.95]
+    out = scan.scan_matrix(m, rows=rows, cds=cds)
+    o = c_oracle.scan(np.ascontiguousarray(m[rows]), cds=cds)
+    r = out.results[0]
+    assert (int(r["seg_sites"]), int(r["H"])) == (o["S"], o["H"]) and out.sfs(0).tolist() == o["sfs"].tolist()
+
+
+def test_unit_at_the_row_limit(gpu):
+    """PFA_MAX_ROWS rows x 16 sites, coding and not, against the C oracle"""
+    from polyfasta_amd import _lib
+    rng = np.random.default_rng(9)
+    n = _lib.PFA_MAX_ROWS
+    m = _many_row_matrix(rng, n, 16, "ACGTN")
+    o = c_oracle.scan(m)
+    r = scan.scan_matrix(m).results[0]
+    assert (int(r["seg_sites"]), int(r["H"]), int(r["sfs_bad"])) == (o["S"], o["H"], o["sfs_bad"])
+    m = _many_row_matrix(rng, n, 15, "ACGT")
+    o = c_oracle.scan(m, cds=True)
+    out = scan.scan_matrix(m, cds=True)
+    r = out.results[0]
+    assert (int(r["seg_sites"]), int(r["H"]), int(r["seg_S"]), int(r["seg_N"]), int(r["H_S"]), int(r["H_N"])) == \
+           (o["S"], o["H"], o["seg_S"], o["seg_N"], o["H_S"], o["H_N"])
+    assert out.sfs(0).tolist() == o["sfs"].tolist()
+
+
 @pytest.mark.parametrize("rows_per_chunk,slots,seed", [(8, 16, 0), (12, 64, 1), (36, 64, 2), (8, 256, 3), (64, 32, 4)])
 def test_tall_kernel_coding_forced_on_small_units(gpu, monkeypatch, rows_per_chunk, slots, seed):
     """The coding variant of the row-chunked kernel forced onto units of any size, with tiny chunks

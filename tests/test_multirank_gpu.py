@@ -58,6 +58,28 @@ def test_two_rank_cli_equals_single_process(gpu, tmp_path, extra):
     assert open(out).read() == want
 
 
+def test_two_rank_cli_writes_the_out_file_like_one_process(gpu, tmp_path):
+    """`-o out.csv` without `-s` as two ranks: header (mode "w") and rows in the file, the progress chatter and the
+    trailing newline on rank 0's stdout only (PolyFastA.py:103, :141-142), byte for byte what one process leaves."""
+    d = _make_dir(tmp_path, n_files=21)
+    one = tmp_path / "one.csv"
+    want_stdout = _single(["-d", str(d), "-o", str(one)])
+    two = tmp_path / "two.csv"
+    out0 = tmp_path / "rank0_stdout.txt"
+    port = dist._free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_cli_rank_worker.py"), str(out0), "-d", str(d), "-o", str(two)],
+                                      env=env, cwd=ROOT, stderr=subprocess.PIPE))
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err.decode()[-3000:]
+    assert open(two).read() == open(one).read()
+    got_stdout = open(out0, newline="").read()           # (universal newlines would turn the chatter's "\r" into "\n")
+    assert got_stdout == want_stdout.replace(str(one), str(two)) and want_stdout.endswith("\n") and "\r Writting to" in got_stdout
+
+
 def test_rccl_comm_one_rank(gpu, tmp_path):
     """pfa_comm_* on librccl with a world of one: unique id through the rendezvous file, barrier,
     max-reduction, host-staged all-gather, and the device-side gather of a plan's records."""
@@ -121,7 +143,8 @@ def test_bench_with_two_ranks_on_one_gpu(gpu):
     gathered, rank 0's share equal to its own fetch"""
     import json
     env = dict(os.environ, PFA_ALLOW_SHARED_GPU="1", PFA_COMM_FACTORY="tests._gloo_comm:GlooComm", PYTHONPATH=ROOT)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "512"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "512",
+                        "--e2e-files-per-rank", "96", "--e2e-reps", "2"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -130,3 +153,7 @@ def test_bench_with_two_ranks_on_one_gpu(gpu):
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3
     assert j["check"]["gathered_records"] == 2 * 512 and j["check"]["gathered_rank0_equals_fetch"] is True
     assert j["value"] > 0 and "cpu_baseline" not in j and "workloads" not in j
+    # the N > 1 end-to-end leg: both ranks drain the shared queue of one directory, rows gathered to rank 0 and oracle-checked
+    e = j["end_to_end"]
+    assert e["ranks"] == 2 and e["files"] == 192 and e["rows_ok"] is True and e["alignments_per_s"] > 0, e
+    assert j["rehearsal"]["shared_gpu"] is True
