@@ -188,7 +188,7 @@ def _many_row_matrix(rng, n, L, alphabet):
     syms = np.frombuffer(alphabet.encode(), dtype=np.uint8)
     for s in range(L):
         k = int(rng.integers(1, 6))
-        al = rng.choice(syms, size=k, replace=False)
+        al = rng.choice(syms, size=k)            # (repeats merge: fewer alleles)
         w = rng.random(k) ** 3 + 1e-4
         m[:, s] = rng.choice(al, size=n, p=w / w.sum())
     return m
