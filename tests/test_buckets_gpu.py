@@ -163,6 +163,58 @@ def test_output_replicas_sum_to_the_oracle(gpu, monkeypatch, replicas):
     dev.free()
 
 
+@pytest.mark.parametrize("shape", ["one_plain", "one_coding", "coding_100_rows", "pops_of_200", "three_small"])
+def test_run_fetch_small_plans(gpu, monkeypatch, shape):
+    """pfa_plan_run_fetch (the one-call latency path) on small single-launch plans of every kernel shape they
+    take — output replicas, the flag-word fetch, slab clearing between calls — repeated, against the oracle,
+    and equal to run() + fetch()."""
+    b = scan.Batch(stride_align=128)
+    checks = []
+    if shape == "one_plain":
+        m = synth.synth_alignment(21, 0, 10000, synth.make_params(50, 0.01))
+        b.add_unit(b.add_matrix(m))
+        checks = [(0, m, False, None)]
+    elif shape == "one_coding":
+        m = synth.synth_alignment(21, 1, 9000, synth.make_params(50, 0.01), coding=True)
+        b.add_unit(b.add_matrix(m), cds=True)
+        checks = [(0, m, True, None)]
+    elif shape == "coding_100_rows":
+        m = synth.synth_alignment(21, 2, 6000, synth.make_params(100, 0.01), coding=True)
+        b.add_unit(b.add_matrix(m), cds=True)
+        checks = [(0, m, True, None)]
+    elif shape == "pops_of_200":
+        m = synth.synth_alignment(21, 3, 100000, synth.make_params(200, 0.01))
+        mid = b.add_matrix(m)
+        for k in range(2):
+            rows = np.arange(k, 200, 2, dtype=np.uint32)
+            b.add_unit(mid, rows=rows)
+            checks.append((k, m, False, rows))
+    else:
+        for k, (n, L) in enumerate([(20, 1000), (50, 3000), (7, 129)]):
+            m = synth.synth_alignment(21, 10 + k, L, synth.make_params(n, 0.05))
+            b.add_unit(b.add_matrix(m))
+            checks.append((k, m, False, None))
+    bases, table = b.pack()
+    dev = scan.DeviceBuffer(len(bases))
+    dev.upload(bases)
+    plan = scan.Plan(table)
+    outs = []
+    for rep in range(4):
+        out = plan.run_fetch(dev)
+        for i, m, cds, rows in checks:
+            _check(out, i, m, cds=cds, rows=rows)
+        outs.append(out)
+    plan.run(dev)                       # the two-call path on the same plan still works after fused calls
+    out = plan.fetch()
+    assert (out.results == outs[0].results).all() and (out.sfs_flat == outs[0].sfs_flat).all()
+    out = plan.run_fetch(dev)
+    assert (out.results == outs[0].results).all() and (out.sfs_flat == outs[0].sfs_flat).all()
+    if outs[0].syn_num is not None:
+        assert (out.syn_num == outs[0].syn_num).all()
+    plan.close()
+    dev.free()
+
+
 @pytest.mark.parametrize("replicas", [4, 32])
 def test_replicas_summed_in_place_for_the_device_side_gather(gpu, monkeypatch, replicas):
     """pfa_plan_results_dev() sums the output replicas IN PLACE (dst == src in sum_replicas_kernel) for the
