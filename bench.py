@@ -133,8 +133,10 @@ def extra_workloads(args):
                     ("N200_plain_200x100000", dict(rows=200, sites=100000, batch=128)),
                     ("N200_coding_200x9000", dict(rows=200, sites=9000, batch=8192, coding=True)),
                     # units with many rows: the row-chunked kernel (and its wide form above 2 048 coding rows)
-                    ("N1000_coding_1000x9000", dict(rows=1000, sites=9000, batch=1024, coding=True)),
-                    ("N5000_coding_5000x9000", dict(rows=5000, sites=9000, batch=256, coding=True)),
+                    # (batches sized so that the launch is several rounds of workgroups deep: a coding chunk is 3 tiles x all rows,
+                    # 3.8 MB at N = 5 000, and 256 units would be 1.3 rounds of the chip's 2 304 wavefront slots)
+                    ("N1000_coding_1000x9000", dict(rows=1000, sites=9000, batch=2048, coding=True)),
+                    ("N5000_coding_5000x9000", dict(rows=5000, sites=9000, batch=1024, coding=True)),
                     # BASELINE configs[4] at its full size on ONE GPU: 100 000 alignments = 50 GB of bases resident in HBM
                     ("C5_batch_100000x50x10000", dict(rows=50, sites=10000, batch=100000))):
         try:
@@ -279,10 +281,11 @@ def end_to_end(args):
                 "rows_ok": rc == 0 and check(rows, bases, M, L, flags),
                 # where the best run's time went (stages overlap: loaders, link and card run concurrently)
                 "stages": {"startup_s (argparse, listdir, sorted, path table)": best - stats["wall_s"] + stats.get("open_s", 0.0),
-                           "read+index_s per loader thread": (stats["read_thread_s"] + stats["index_thread_s"]) / nt,
+                           "read_s per loader thread": stats["read_thread_s"] / nt,
                            "loader_threads": nt, "read_GBps_all_threads": stats["bytes_read"] / max(stats["read_thread_s"] / nt, 1e-9) / 1e9,
                            "h2d_busy_s": stats["copy_busy_s"], "h2d_GBps_while_busy": stats["bytes_copied"] / max(stats["copy_busy_s"], 1e-9) / 1e9,
-                           "repack+plan+scan launch_s": stats["repack_plan_s"], "wait_for_scan_s": stats["fetch_wait_s"],
+                           "index+pack+copy_s per loader thread": stats["index_thread_s"] / nt, "turn / slot wait_s per loader thread": stats["turn_wait_thread_s"] / nt,
+                           "transport_bytes / text_bytes": stats["bytes_copied"] / max(stats["bytes_read"], 1), "wait_for_scan_s": stats["fetch_wait_s"],
                            "rows+emit_s": stats["rows_s"] + stats["flush_s"], "batches": stats["batches"]}}
         report.update({k: report["plain"][k] for k in ("alignments_per_s", "seconds", "files", "text_GBps", "rows_ok")})
         report["loader_threads"] = report["plain"]["stages"]["loader_threads"]

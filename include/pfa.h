@@ -296,6 +296,11 @@ typedef struct pfa_fasta_row {
   uint64_t seq_off;  /* into text (after the call) */
 } pfa_fasta_row;
 int64_t pfa_fasta_index_compact(uint8_t* text, uint64_t n_text, pfa_fasta_row* rows, uint64_t cap);
+/* The transport form of a row of the streaming ingest: `n` bases -> ceil(n/4) bytes, two bits per
+ * base (A 0, C 1, T 2, G 3 = (byte >> 1) & 3 after case folding; base i of a group of four in bits
+ * 2i+1..2i).  Returns 1, or 0 when some byte is not A/C/G/T/a/c/g/t (such a row travels as text:
+ * every distinct byte is an allele, PolyFastA.py:258).  The card expands it (repack_kernel). */
+int pfa_fasta_pack2(const uint8_t* src, uint64_t n, uint8_t* dst);
 
 /* Batch loader: read, index and pack `n_files` FASTA files with `n_threads`
  * host threads (0 = 16) into `bases_out` (capacity `cap` bytes); matrices are
@@ -357,16 +362,20 @@ int pfa_format_double(double x, char* out32);
  * The feeder of the scan for the reference's file loop (PolyFastA.py:104-140,
  * readfasta :227-250, population split :122-134), built so that the PCIe link is
  * the only thing a directory of alignments waits for:
- *   loader threads   read() each file ONCE, straight into a ring of pinned slots,
- *                    index it in place (pfa_fasta_index_compact) and match the
- *                    --pops keys against its record names;
+ *   loader threads   read() each file ONCE, index it in place
+ *                    (pfa_fasta_index_compact), match the --pops keys against its
+ *                    record names, and copy its rows in transport form — two bits
+ *                    per base for clean A/C/G/T rows (pfa_fasta_pack2), the bytes
+ *                    otherwise — into a ring of pinned slots, in feed order;
  *   uploader thread  copies every slot to the card as soon as its files have
  *                    landed (own HIP stream, at most two copies in flight);
  *   the caller       (pfa_ingest_next) takes whatever has been uploaded, lets the
- *                    card turn the raw text into row-major upper-case matrices
+ *                    card expand the rows into row-major upper-case matrices
  *                    (repack_kernel: one pass at HBM speed), builds the scan plan
  *                    of those files and launches it.
- * Files are handed out in feed order, so batches are consecutive runs of it.
+ * Files are placed in the ring as their loaders finish, so a batch is a SET of feed
+ * positions (ascending inside the batch), not a run of them: a caller that prints in
+ * feed order holds rows back until the positions before them have arrived.
  * Nothing here scans on the CPU. */
 typedef struct pfa_ingest pfa_ingest;
 typedef struct pfa_ingest_opts {
@@ -375,20 +384,20 @@ typedef struct pfa_ingest_opts {
   uint32_t unit_flags;    /* PFA_FLAG_CDS or 0: flags of every scan unit */
   uint32_t n_keys;        /* --pops keys (0: one unit per file) */
   const char* const* keys;/* NUL-terminated byte strings, matched as substrings of the record names */
-  uint64_t slot_bytes;    /* size of a pinned slot = one H2D copy; 0 = 64 MiB (less for small inputs) */
-  uint32_t n_slots;       /* pinned slots; 0 = 4 */
+  uint64_t slot_bytes;    /* size of a pinned slot = one H2D copy; 0 = 16 MiB (less for small inputs) */
+  uint32_t n_slots;       /* pinned slots; 0 = 8 */
   uint32_t reserved;
 } pfa_ingest_opts;
 
 #define PFA_NO_KEY 0xFFFFFFFFu
 #define PFA_BATCH_REGULAR 1u /* every file packed, every key found, coding lengths multiples of 3 */
 
-/* One batch = a run of consecutive files of the feed order.  Every pointer is owned
+/* One batch = some files of the feed order, ascending.  Every pointer is owned
  * by the ingest and valid until the next pfa_ingest_next() / pfa_ingest_close(). */
 typedef struct pfa_ingest_batch {
   uint32_t n_files;
   uint32_t n_units;          /* scan units = CSV rows */
-  uint32_t first_pos;        /* feed position of the batch's first file */
+  uint32_t first_pos;        /* lowest feed position in the batch */
   uint32_t flags;            /* PFA_BATCH_* */
   const uint32_t* file_idx;  /* [n_files] index into the `paths` of pfa_ingest_open() */
   const int32_t* status;     /* [n_files] 0 = packed, PFA_FILE_NOT_FASTA, PFA_FILE_UNEQUAL, PFA_ERR_IO */
@@ -414,9 +423,10 @@ uint32_t pfa_ingest_backlog(const pfa_ingest* ing);
 /* blocks until at least one uploaded slot is there; 1 = batch, 0 = every fed file has been
  * handed out and the last feed was marked `last`, < 0 = error */
 int pfa_ingest_next(pfa_ingest* ing, pfa_ingest_batch* out);
-/* [0] seconds the loader threads spent in read(), [1] in the index pass, [2] bytes read,
- * [3] seconds the uploader had copies in flight, [4] bytes copied, [5] loader threads,
- * [6] seconds in repack launches + plan creation, [7] batches */
+/* [0] seconds the loader threads spent in read(), [1] indexing, packing rows and copying them into
+ * the ring, [2] bytes read, [3] seconds the uploader had copies in flight, [4] bytes copied
+ * (transport bytes), [5] loader threads, [6] seconds the loader threads waited for their turn or a
+ * free slot, [7] batches */
 int pfa_ingest_stats(const pfa_ingest* ing, double* out8);
 /* display names (the text after the last '/', PolyFastA.py:110) of every path of
  * pfa_ingest_open(): name f = blob[off[f] .. off[f+1]); owned by the ingest */

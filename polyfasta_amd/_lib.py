@@ -145,6 +145,7 @@ _PROTOTYPES = {
     "pfa_fasta_load_files": (ctypes.c_int, [_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _vp,
                                             ctypes.c_uint64, _vp, _vp, ctypes.c_uint64, u64p, u64p]),
     "pfa_fasta_index_compact": (ctypes.c_int64, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint64]),
+    "pfa_fasta_pack2": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp]),
     "pfa_ingest_open": (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, ctypes.POINTER(IngestOptsC), ctypes.POINTER(_vp)]),
     "pfa_ingest_feed": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_int]),
     "pfa_ingest_backlog": (ctypes.c_uint32, [_vp]),

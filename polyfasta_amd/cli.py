@@ -393,6 +393,17 @@ class RowBlock:
         return RowBlock(self.meta[order], self.rec[order], None if self.syn is None else self.syn[order],
                         None if self.sfs is None else [self.sfs[i] for i in order.tolist()], self.specials)
 
+    def split_below(self, fidx_end):
+        """(rows and special lines of files < fidx_end, the rest); self is sorted"""
+        k = int(np.searchsorted(self.meta["fidx"], fidx_end, side="left"))
+        lo = [x for x in self.specials if x[0] < fidx_end]
+        hi = [x for x in self.specials if x[0] >= fidx_end]
+        part = lambda a, b: RowBlock(self.meta[a:b], self.rec[a:b], None if self.syn is None else self.syn[a:b],   # noqa: E731
+                                     None if self.sfs is None else self.sfs[a:b], None)
+        first, rest = part(0, k), part(k, len(self.meta))
+        first.specials, rest.specials = lo, hi
+        return first, rest
+
     def to_bytes(self):
         import pickle
         return pickle.dumps((self.meta.tobytes(), self.rec.tobytes(), None if self.syn is None else self.syn.tobytes(),
@@ -554,6 +565,10 @@ def run_files(paths, args, sink, rank, world, comm, wq, keys):
                     drained[0] = True
                 ing.feed(got, last=not got)
         kept = []
+        # one rank prints as it goes, in file order: batches hold SETS of files (the loaders place them as they
+        # finish), so rows wait in `kept` until every file before them has arrived
+        arrived = np.zeros(len(paths) + 1, dtype=bool)
+        upto = 0
         t_fetch = t_emit = 0.0
         while True:
             top_up()
@@ -565,10 +580,16 @@ def run_files(paths, args, sink, rank, world, comm, wq, keys):
             res, syn, sfs_flat = b.fetch(args.cds, want_sfs=args.sfs)
             t2 = time.perf_counter()
             blk = block_from_batch(b, res, syn, sfs_flat, args, paths, keys)
+            kept.append(blk)
             if world == 1:
-                emit_block(blk, sink, args, ing.table, paths, keys)
-            else:
-                kept.append(blk)
+                arrived[b.file_idx] = True
+                new_upto = upto + int(np.argmin(arrived[upto:]))        # first file that has not arrived yet
+                if new_upto > upto:
+                    upto = new_upto
+                    allb = RowBlock.concat(kept, args.cds).sorted()
+                    ready = allb.split_below(upto)
+                    kept = [ready[1]]
+                    emit_block(ready[0], sink, args, ing.table, paths, keys)
             t3 = time.perf_counter()
             t_fetch += t2 - t1
             t_emit += t3 - t2

@@ -21,6 +21,9 @@
 #include <sys/stat.h>
 
 #include <new>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -162,6 +165,72 @@ int64_t index_compact(uint8_t* text, uint64_t n_text, std::vector<pfa_fasta_row>
 
 }  // namespace pfa
 
+// ---- 2-bit transport rows (pfa_ingest.hip) --------------------------------------
+// A row that holds nothing but A/C/G/T (either case) crosses PCIe as two bits per base — the card
+// expands it to the upper-case bytes readfasta would have produced (repack_kernel) — so the link
+// carries a quarter of the text.  Code = (byte >> 1) & 3 after case folding: A 0, C 1, T 2, G 3 (the
+// kernels' codon base order); base i of a group of four sits in bits 2i+1..2i of its byte.  Any other
+// byte makes the row travel as it is (every distinct byte is an allele, PolyFastA.py:258).
+namespace pfa {
+
+static bool pack2_scalar(const uint8_t* src, uint64_t n, uint8_t* dst) {
+  static const uint8_t canon[4] = {'A', 'C', 'T', 'G'};
+  uint32_t bad = 0;
+  uint64_t i = 0;
+  for (; i + 4 <= n; i += 4) {
+    uint32_t b = 0;
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t u = src[i + k] & 0xDFu, c = (u >> 1) & 3u;
+      bad |= canon[c] ^ u;
+      b |= c << (2 * k);
+    }
+    dst[i >> 2] = (uint8_t)b;
+  }
+  if (i < n) {
+    uint32_t b = 0;
+    for (uint32_t k = 0; i + k < n; ++k) {
+      const uint32_t u = src[i + k] & 0xDFu, c = (u >> 1) & 3u;
+      bad |= canon[c] ^ u;
+      b |= c << (2 * k);
+    }
+    dst[i >> 2] = (uint8_t)b;
+  }
+  return bad == 0;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static bool pack2_avx2(const uint8_t* src, uint64_t n, uint8_t* dst) {
+  const __m256i fold = _mm256_set1_epi8((char)0xDF), three = _mm256_set1_epi8(3);
+  const __m256i canon = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+  const __m256i w8 = _mm256_set1_epi16(0x0401), w16 = _mm256_set1_epi32(0x00100001);
+  const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+  __m256i bad = _mm256_setzero_si256();
+  uint64_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    const __m256i u = _mm256_and_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i)), fold);
+    const __m256i c = _mm256_and_si256(_mm256_srli_epi16(u, 1), three);
+    bad = _mm256_or_si256(bad, _mm256_xor_si256(_mm256_shuffle_epi8(canon, c), u));
+    const __m256i t = _mm256_madd_epi16(_mm256_maddubs_epi16(c, w8), w16);        // one packed byte per 32-bit lane
+    const __m256i q = _mm256_shuffle_epi8(t, pick);                               // 4 bytes at the bottom of each 128-bit half
+    const uint32_t lo = (uint32_t)_mm256_cvtsi256_si32(q), hi = (uint32_t)_mm256_extract_epi32(q, 4);
+    memcpy(dst + (i >> 2), &lo, 4);
+    memcpy(dst + (i >> 2) + 4, &hi, 4);
+  }
+  const bool ok_tail = i == n || pack2_scalar(src + i, n - i, dst + (i >> 2));
+  return ok_tail && _mm256_testz_si256(bad, bad);
+}
+#endif
+
+bool pack2_row(const uint8_t* src, uint64_t n, uint8_t* dst) {
+#if defined(__x86_64__)
+  static const bool have_avx2 = __builtin_cpu_supports("avx2");
+  if (have_avx2) return pack2_avx2(src, n, dst);
+#endif
+  return pack2_scalar(src, n, dst);
+}
+
+}  // namespace pfa
+
 extern "C" {
 
 static int64_t fasta_index_impl(const uint8_t* text, uint64_t n_text, pfa_fasta_rec* recs, uint64_t cap) {
@@ -249,6 +318,11 @@ int64_t pfa_fasta_index_compact(uint8_t* text, uint64_t n_text, pfa_fasta_row* r
     pfa::set_error("pfa_fasta_index_compact: unexpected exception");
     return PFA_ERR_ARG;
   }
+}
+
+int pfa_fasta_pack2(const uint8_t* src, uint64_t n, uint8_t* dst) {
+  if ((!src || !dst) && n) { pfa::set_error("pfa_fasta_pack2: NULL argument"); return PFA_ERR_ARG; }
+  return pfa::pack2_row(src, n, dst) ? 1 : 0;
 }
 
 int pfa_fasta_pack(const uint8_t* text, uint64_t n_text, const pfa_fasta_rec* recs, uint64_t n_recs,

@@ -25,4 +25,8 @@ struct IndexScratch {
 // of raw bytes.  Returns the record count, PFA_ERR_FORMAT for "not FASTA".
 int64_t index_compact(uint8_t* text, uint64_t n_text, std::vector<pfa_fasta_row>& rows, IndexScratch& sc);
 
+// `n` bases -> ceil(n / 4) bytes, two bits per base (A 0, C 1, T 2, G 3; case folded); false (and `dst`
+// undefined) when a byte is not A/C/G/T/a/c/g/t
+bool pack2_row(const uint8_t* src, uint64_t n, uint8_t* dst);
+
 }  // namespace pfa

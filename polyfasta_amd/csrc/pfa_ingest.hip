@@ -4,20 +4,24 @@
 //
 // What limits files -> CSV is the PCIe link (57 GB/s measured on this pool), provided the host
 // touches every byte once and the card never waits for a whole batch:
-//   loader threads  claim the files in feed order, read() each one ONCE straight into a ring of
-//                   pinned slots (no temporary buffer), index it in place (index_compact: one
-//                   memchr pass; nothing is copied for single-line records) and match the --pops
-//                   keys against its record names.  16 threads read 110 GB/s from tmpfs; more
-//                   threads only fight over the memory controllers (tools/ubench/ingest_probe.hip).
+//   loader threads  claim the files in feed order, read() each one ONCE into a buffer that stays in
+//                   their core's L2, index it in place (index_compact: one memchr pass) and match the
+//                   --pops keys against its record names; then every row is turned into its TRANSPORT
+//                   form — two bits per base when it holds nothing but A/C/G/T (pack2_row, AVX2), the
+//                   bytes as they are otherwise — and the file's rows are copied, in feed order, into a
+//                   ring of pinned slots.  The link then carries a quarter of the text: 57 GB/s of PCIe
+//                   (measured) stop being the bound of files -> CSV; the host's read() rate is.
+//                   (16 threads read 110 GB/s from tmpfs; more only fight over the memory controllers:
+//                   tools/ubench/ingest_probe.hip.  PFA_INGEST_TRANSPORT=raw: no packing, for A/B runs.)
 //   uploader thread copies a slot to the card as soon as its files have landed, on its own stream,
 //                   two copies in flight at most: the link never idles while there is text.
 //   pfa_ingest_next (the caller's thread) takes whatever has been uploaded since its last call,
 //                   lets the card turn the raw text into row-major, stride-aligned, upper-case
 //                   matrices (repack_kernel below: 1 MB of HBM traffic per 500 KB alignment,
 //                   nothing at 6 TB/s), and creates and launches the scan plan of those files.
-// The rows of a record reach the card as (offset, length) pairs; upper-casing and the test for
-// bytes >= 0x80 (outside the one-byte-per-base contract) happen in repack_kernel, which reads
-// every byte anyway.  Nothing here scans on the CPU.
+// The rows of a record reach the card as (offset, length, form) triples; expansion of packed rows,
+// upper-casing of the others and the test for bytes >= 0x80 (outside the one-byte-per-base contract)
+// happen in repack_kernel, which writes every byte of the matrices anyway.  Nothing here scans on the CPU.
 #include <fcntl.h>
 #include <sched.h>
 #include <string.h>
@@ -46,8 +50,9 @@ struct Seg {
   unsigned long long src;
   unsigned long long dst;
   uint32_t len;
-  uint32_t file;   // index into the batch's `bad` words
+  uint32_t file;   // index into the batch's `bad` words | kSegPacked: the run is 2 bits per base
 };
+static constexpr uint32_t kSegPacked = 0x80000000u;
 
 __device__ inline uint32_t swar_upper(uint32_t w) {
   const uint32_t h = w & 0x7F7F7F7Fu;
@@ -74,6 +79,30 @@ __global__ void __launch_bounds__(256) repack_kernel(const uint8_t* __restrict__
     if (stride < 16u) stride = 16u;
     const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
     uint32_t seen = 0u;
+    if (g.file & kSegPacked) {
+      // two bits per base (pack2_row: A 0, C 1, T 2, G 3): one dword in, sixteen upper-case bytes out.
+      // The four codes of a byte are spread over the four selector bytes of a v_perm_b32 that picks
+      // 'A' 'C' 'T' 'G' out of one constant word: nibbles to 16-bit spacing (b * 0x1001: the two copies do
+      // not overlap, so the product is their OR), then codes to 8-bit spacing (t * 0x41, likewise).
+      const uint32_t* const in = reinterpret_cast<const uint32_t*>(src);   // rows start on 16 bytes
+      for (uint32_t i = threadIdx.x * 16u; i < stride; i += 256u * 16u) {
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (i < len) {
+          const uint32_t w = in[i >> 4];
+          uint32_t q[4];
+#pragma unroll
+          for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t t = (((w >> (8u * k)) & 0xFFu) * 0x1001u) & 0x000F000Fu;
+            const uint32_t sel = (t * 0x41u) & 0x03030303u;
+            const uint32_t have = len - i > 4u * k ? len - i - 4u * k : 0u;
+            q[k] = __builtin_amdgcn_perm(0u, 0x47544341u, sel) & (have >= 4u ? 0xFFFFFFFFu : (1u << (8u * have)) - 1u);
+          }
+          o = u32x4{q[0], q[1], q[2], q[3]};
+        }
+        *reinterpret_cast<u32x4*>(dst + i) = o;
+      }
+      continue;
+    }
     for (uint32_t i = threadIdx.x * 16u; i < stride; i += 256u * 16u) {
       u32x4 o = {0u, 0u, 0u, 0u};
       if (i < len) {
@@ -98,17 +127,21 @@ __global__ void __launch_bounds__(256) repack_kernel(const uint8_t* __restrict__
       }
       *reinterpret_cast<u32x4*>(dst + i) = o;
     }
-    if (seen & 0x80808080u) bad[g.file] = 1u;
+    if (seen & 0x80808080u) bad[g.file] = 1u;   // (kSegPacked is clear here)
   }
 }
 
 namespace {
 
-constexpr size_t kDefaultSlot = size_t(64) << 20;
+// a slot = one H2D copy of TRANSPORT bytes (a quarter of the text for clean A/C/G/T rows): 16 MiB is
+// 128 alignments of 50 x 10 kb and copies at 55 of the link's 57.5 GB/s
+constexpr size_t kDefaultSlot = size_t(16) << 20;
 constexpr size_t kMinSlot = size_t(256) << 10;
-constexpr size_t kRampSlot = size_t(8) << 20;
-constexpr uint32_t kDefaultSlots = 4;
-constexpr size_t kMaxBatchBytes = size_t(512) << 20;
+constexpr size_t kRampSlot = size_t(2) << 20;
+constexpr uint32_t kDefaultSlots = 8;
+constexpr size_t kMaxBatchBytes = size_t(128) << 20;
+constexpr uint64_t kRowPacked = 1ull << 63;   // FileRec::row_off: the row travels two bits per base
+inline size_t up16(size_t x) { return (x + 15u) & ~size_t(15); }
 constexpr int kBatchEvents = 64;
 
 inline size_t up256(size_t x) { return (x + 255u) & ~size_t(255); }
@@ -144,7 +177,7 @@ struct FileRec {
   int32_t status = 0;
   uint32_t n_rows = 0, n_sites = 0;
   uint32_t use = 0;
-  std::vector<uint64_t> row_off;    // per record: offset of its sequence run in the use's buffer (status 0)
+  std::vector<uint64_t> row_off;    // per record: offset of its transport run in the use's buffer | kRowPacked (status 0)
   std::vector<uint32_t> key_cnt;    // per key: matching records
   std::vector<uint32_t> key_rows;   // their indices, key after key
 };
@@ -154,7 +187,7 @@ struct Use {
   uint8_t* h = nullptr;
   uint8_t* d = nullptr;
   size_t cap = 0, used = 0;
-  uint32_t first_pos = 0, n_pos = 0;
+  std::vector<uint32_t> pos;   // feed positions of its files, in the order they were placed
   uint32_t pending = 0;   // files placed here that are still being read / indexed
   int host_slot = -1, dev_slot = -1;
   bool big = false, sealed = false, ready = false, enqueued = false, consumed = false;
@@ -175,16 +208,18 @@ struct pfa_ingest {
   std::vector<uint64_t> names_off;
   std::vector<std::string> keys;
   uint32_t stride_align = 128, unit_flags = 0, want_threads = 0, n_slots = pfa::kDefaultSlots, n_dev_slots = 2 * pfa::kDefaultSlots;
+  bool pack_rows = true;
   size_t max_slot = pfa::kDefaultSlot;
   int device = 0;
 
   // ---- pipeline state (mu)
   std::mutex mu;
-  std::condition_variable cv_work, cv_turn, cv_slot, cv_up, cv_batch, cv_consumed;
+  std::condition_variable cv_work, cv_slot, cv_open, cv_up, cv_batch, cv_consumed;
+  bool opening = false;                // a loader is opening the next use
   std::vector<uint32_t> feed;          // feed order: indices into paths
   std::deque<pfa::FileRec> files;      // by feed position
   bool feed_closed = false, stop = false;
-  uint32_t next_claim = 0, turn = 0;
+  uint32_t next_claim = 0, n_placed = 0, n_handed = 0;   // files claimed by a loader / placed in the ring / handed out in batches
   std::deque<pfa::Use> uses;
   int open_use = -1;
   size_t slot_bytes = 0;               // decided by the first reservation
@@ -217,7 +252,7 @@ struct pfa_ingest {
   bool launched = false;                      // something of the current batch sits on the context stream
 
   // ---- statistics
-  std::atomic<uint64_t> ns_read{0}, ns_index{0}, bytes_read{0}, ns_copy{0}, bytes_copied{0}, ns_main{0};
+  std::atomic<uint64_t> ns_read{0}, ns_index{0}, bytes_read{0}, ns_copy{0}, bytes_copied{0}, ns_main{0}, ns_wait{0};
 };
 
 namespace pfa {
@@ -226,7 +261,7 @@ namespace {
 void fail(pfa_ingest* g, int rc, const std::string& msg) {   // mu held
   if (g->hard_rc == 0) { g->hard_rc = rc; g->hard_error = msg; }
   g->stop = true;
-  g->cv_work.notify_all(); g->cv_turn.notify_all(); g->cv_slot.notify_all();
+  g->cv_work.notify_all(); g->cv_slot.notify_all(); g->cv_open.notify_all();
   g->cv_up.notify_all(); g->cv_batch.notify_all(); g->cv_consumed.notify_all();
 }
 
@@ -237,7 +272,7 @@ hipEvent_t take_event(pfa_ingest* g) {   // mu held
   return e;
 }
 
-bool all_reserved(const pfa_ingest* g) { return g->turn == g->feed.size(); }
+bool all_reserved(const pfa_ingest* g) { return g->n_placed == g->feed.size(); }
 
 void seal(pfa_ingest* g, int u) {   // mu held
   if (u < 0) return;
@@ -293,7 +328,6 @@ int new_use(pfa_ingest* g, std::unique_lock<std::mutex>& lk, size_t need, uint32
     }
   }
   Use u;
-  u.first_pos = pos;
   if (need > g->slot_bytes) {   // a file larger than a slot travels alone, in buffers of its own
     u.big = true;
     lk.unlock();
@@ -331,20 +365,29 @@ int new_use(pfa_ingest* g, std::unique_lock<std::mutex>& lk, size_t need, uint32
   return idx;
 }
 
-// the file of feed position `pos` gets `size` bytes in the pinned ring (in feed order: batches are
-// consecutive runs of it); returns its use and offset, or false when the ingest is stopping
+// The file of feed position `pos` gets `size` bytes in the pinned ring, in the order the loaders finish
+// (NOT in feed order: handing a turn from thread to sleeping thread costs ~10 us, i.e. caps the ingest
+// at ~100 k files/s, and every loader would run at the pace of the slowest file before it).  A batch is
+// therefore a SET of feed positions; whoever prints rows in file order holds the stragglers' successors
+// back for a batch (cli.run_files).  Returns false when the ingest is stopping.
 bool reserve(pfa_ingest* g, uint32_t pos, size_t size, uint32_t* use_out, size_t* off_out, uint8_t** text_out) {
   const size_t need = up256(std::max<size_t>(size, 1));
   std::unique_lock<std::mutex> lk(g->mu);
-  while (!g->stop && g->turn != pos) g->cv_turn.wait(lk);
-  if (g->stop) return false;
-  int u = g->open_use;
-  if (u < 0 || need > g->slot_bytes || g->uses[(size_t)u].used + need > g->uses[(size_t)u].cap) {
-    seal(g, g->open_use);
-    g->open_use = -1;
+  int u;
+  for (;;) {
+    if (g->stop) return false;
+    if (g->opening) { g->cv_open.wait(lk); continue; }     // somebody is opening the next use (it may wait for a free slot)
+    u = g->open_use;
+    if (u >= 0 && need <= g->slot_bytes && g->uses[(size_t)u].used + need <= g->uses[(size_t)u].cap) break;
+    // this file starts a new use (or, larger than a slot, travels in buffers of its own); one thread at a time
+    g->opening = true;
+    if (u < 0 || need <= g->slot_bytes) { seal(g, g->open_use); g->open_use = -1; }
     u = new_use(g, lk, need, pos);
+    g->opening = false;
+    g->cv_open.notify_all();
     if (u < 0) return false;
     if (!g->uses[(size_t)u].big) g->open_use = u;
+    break;
   }
   Use& s = g->uses[(size_t)u];
   *use_out = (uint32_t)u;
@@ -352,14 +395,13 @@ bool reserve(pfa_ingest* g, uint32_t pos, size_t size, uint32_t* use_out, size_t
   *text_out = s.h + s.used;
   s.used += need;
   s.pending += 1;
-  s.n_pos += 1;
+  s.pos.push_back(pos);
   g->files[pos].use = (uint32_t)u;
   if (s.big) seal(g, u);
-  g->turn += 1;
+  g->n_placed += 1;
   // nothing further to place for now: let what has been read travel (a rank between two claims
   // of the shared queue must not sit on a half-filled slot)
   if (all_reserved(g)) { seal(g, g->open_use); g->open_use = -1; }
-  g->cv_turn.notify_all();
   return true;
 }
 
@@ -374,6 +416,7 @@ void worker_body(pfa_ingest* g) {
   (void)hipSetDevice(g->device);
   IndexScratch sc;
   std::vector<pfa_fasta_row> rows;
+  std::vector<uint8_t> text, image;    // the file as read; its rows in transport form (reused from file to file)
   for (;;) {
     uint32_t pos;
     FileRec* fp;
@@ -398,15 +441,13 @@ void worker_body(pfa_ingest* g) {
       else size = (size_t)sb.st_size;
     }
     if (fd < 0) f.status = PFA_ERR_IO;
-    uint32_t use = 0;
-    size_t off = 0;
-    uint8_t* text = nullptr;
-    if (!reserve(g, pos, size, &use, &off, &text)) { if (fd >= 0) close(fd); return; }
+    size_t image_bytes = 0;
     if (fd >= 0) {
       const double t0 = now_s();
+      if (text.size() < size) text.resize(size);
       size_t got = 0;
       while (got < size) {
-        const ssize_t r = read(fd, text + got, size - got);
+        const ssize_t r = read(fd, text.data() + got, size - got);
         if (r <= 0) break;
         got += (size_t)r;
       }
@@ -416,7 +457,7 @@ void worker_body(pfa_ingest* g) {
       g->ns_read += (uint64_t)((t1 - t0) * 1e9);
       g->bytes_read += got;
       if (f.status == 0) {
-        const int64_t n = index_compact(text, size, rows, sc);
+        const int64_t n = index_compact(text.data(), size, rows, sc);
         if (n == PFA_ERR_FORMAT && strncmp(pfa_last_error(), "not FASTA", 9) == 0) {
           f.status = PFA_FILE_NOT_FASTA;
         } else if (n < 0) {
@@ -428,14 +469,29 @@ void worker_body(pfa_ingest* g) {
           for (const pfa_fasta_row& r : rows)
             if (r.seq_len != f.n_sites) { f.status = PFA_FILE_UNEQUAL; break; }   // PolyFastA.py:111-112
           if (f.status == 0) {
+            // the rows in transport form, each on a 16-byte boundary: two bits per base when the row is
+            // clean A/C/G/T, its bytes otherwise
+            const size_t L = f.n_sites, raw16 = up16(L), packed16 = up16((L + 3u) / 4u);
+            if (image.size() < rows.size() * raw16 + 64u) image.resize(rows.size() * raw16 + 64u);
             f.row_off.resize(rows.size());
-            for (size_t i = 0; i < rows.size(); ++i) f.row_off[i] = off + rows[i].seq_off;
+            for (size_t i = 0; i < rows.size(); ++i) {
+              const uint8_t* src = text.data() + rows[i].seq_off;
+              uint8_t* dst = image.data() + image_bytes;
+              if (L && g->pack_rows && pack2_row(src, L, dst)) {
+                f.row_off[i] = image_bytes | kRowPacked;
+                image_bytes += packed16;
+              } else {
+                if (L) memcpy(dst, src, L);
+                f.row_off[i] = image_bytes;
+                image_bytes += raw16;
+              }
+            }
             if (!g->keys.empty()) {   // PolyFastA.py:125: `pop in header`, a substring match, in record order
               f.key_cnt.assign(g->keys.size(), 0u);
               for (size_t k = 0; k < g->keys.size(); ++k) {
                 const std::string& key = g->keys[k];
                 for (size_t i = 0; i < rows.size(); ++i) {
-                  const char* nm = reinterpret_cast<const char*>(text + rows[i].name_off);
+                  const char* nm = reinterpret_cast<const char*>(text.data() + rows[i].name_off);
                   if (key.empty() || memmem(nm, rows[i].name_len, key.data(), key.size()) != nullptr) {
                     f.key_rows.push_back((uint32_t)i);
                     f.key_cnt[k] += 1;
@@ -448,6 +504,17 @@ void worker_body(pfa_ingest* g) {
         g->ns_index += (uint64_t)((now_s() - t1) * 1e9);
       }
     }
+    // its place in the pinned ring, in feed order (batches are consecutive runs of the feed order)
+    uint32_t use = 0;
+    size_t off = 0;
+    uint8_t* dst = nullptr;
+    const double tw = now_s();
+    if (!reserve(g, pos, image_bytes, &use, &off, &dst)) return;
+    const double tc = now_s();
+    g->ns_wait += (uint64_t)((tc - tw) * 1e9);
+    if (image_bytes) memcpy(dst, image.data(), image_bytes);
+    for (uint64_t& o : f.row_off) o += off;       // (the flag bit stays where it is)
+    g->ns_index += (uint64_t)((now_s() - tc) * 1e9);
     finish(g, use);
   }
 }
@@ -479,7 +546,7 @@ void uploader_body(pfa_ingest* g) {
     if (e != hipSuccess) { fail(g, PFA_ERR_HIP, std::string("ingest: H2D copy failed: ") + hipGetErrorString(e)); return; }
     Use& s = g->uses[u];
     if (s.host_slot >= 0) { g->slot_user[(size_t)s.host_slot] = -1; g->cv_slot.notify_all(); }
-    else g->big_pinned_done.push_back(Pinned{s.h, s.cap});
+    else { g->big_pinned_done.push_back(Pinned{s.h, s.cap}); s.h = nullptr; }   // (handed on exactly once: close() only gives what is left)
     inflight.pop_front();
     if (inflight.empty()) g->ns_copy += (uint64_t)((now_s() - t_busy0) * 1e9);
   };
@@ -595,6 +662,7 @@ int pfa_ingest_open(const char* const* paths, uint32_t n_files, const pfa_ingest
     g->n_slots = o.n_slots ? std::min(std::max(o.n_slots, 2u), 64u) : pfa::kDefaultSlots;
     g->n_dev_slots = 2 * g->n_slots;
     g->max_slot = o.slot_bytes ? std::max<size_t>(pfa::up256((size_t)o.slot_bytes), 4096) : pfa::kDefaultSlot;
+    if (const char* e = getenv("PFA_INGEST_TRANSPORT")) g->pack_rows = strcmp(e, "raw") != 0;
     if (const char* e = getenv("PFA_INGEST_SLOTS")) { const long v = strtol(e, nullptr, 10); if (v >= 2 && v <= 64) { g->n_slots = (uint32_t)v; g->n_dev_slots = 2 * g->n_slots; } }
     if (const char* e = getenv("PFA_INGEST_SLOT_BYTES")) { const long long v = strtoll(e, nullptr, 10); if (v > 0) g->max_slot = std::max<size_t>(pfa::up256((size_t)v), 4096); }
     g->device = pfa::ctx().device;
@@ -654,9 +722,7 @@ uint32_t pfa_ingest_backlog(const pfa_ingest* g) {
   if (!g) return 0;
   pfa_ingest* m = const_cast<pfa_ingest*>(g);
   std::lock_guard<std::mutex> lk(m->mu);
-  uint32_t handed = 0;
-  if (g->consumed) { const pfa::Use& u = g->uses[g->consumed - 1]; handed = u.first_pos + u.n_pos; }
-  return (uint32_t)g->feed.size() - handed;
+  return (uint32_t)g->feed.size() - g->n_handed;
 }
 
 static void release_batch(pfa_ingest* g) {
@@ -680,8 +746,9 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
   release_batch(g);
   const double t_in = pfa::now_s();
   uint32_t lo, hi;
-  struct View { uint8_t* d; bool big; uint32_t first_pos, n_pos; hipEvent_t ev; };
+  struct View { uint8_t* d; bool big; hipEvent_t ev; };
   std::vector<View> uv;
+  std::vector<uint32_t> bpos;   // the batch's feed positions
   {
     std::unique_lock<std::mutex> lk(g->mu);
     for (;;) {
@@ -701,19 +768,33 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
       size_t bytes = g->uses[lo].used;
       while (hi < g->uploaded && !g->uses[hi].big && bytes + g->uses[hi].used <= pfa::kMaxBatchBytes) { bytes += g->uses[hi].used; ++hi; }
     }
-    for (uint32_t u = lo; u < hi; ++u) uv.push_back(View{g->uses[u].d, g->uses[u].big, g->uses[u].first_pos, g->uses[u].n_pos, g->uses[u].ev});
+    for (uint32_t u = lo; u < hi; ++u) {
+      uv.push_back(View{g->uses[u].d, g->uses[u].big, g->uses[u].ev});
+      bpos.insert(bpos.end(), g->uses[u].pos.begin(), g->uses[u].pos.end());
+    }
+  }
+  if (getenv("PFA_INGEST_DEBUG")) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    for (uint32_t u = lo; u < hi; ++u) {
+      const pfa::Use& s = g->uses[u];
+      fprintf(stderr, "ingest batch %u: use %u big=%d host_slot=%d dev_slot=%d d=+%zu used=%zu cap=%zu files:", g->n_batches, u, (int)s.big, s.host_slot, s.dev_slot,
+              s.big ? (size_t)0 : (size_t)(s.d - g->d_text), s.used, s.cap);
+      for (uint32_t p : s.pos) fprintf(stderr, " %u", p);
+      fprintf(stderr, "\n");
+    }
   }
   try {
-    const uint32_t p0 = uv.front().first_pos, p1 = uv.back().first_pos + uv.back().n_pos;
-    const uint32_t nf = p1 - p0, nk = (uint32_t)g->keys.size();
+    std::sort(bpos.begin(), bpos.end());     // within a batch: feed order
+    const uint32_t nf = (uint32_t)bpos.size(), nk = (uint32_t)g->keys.size();
+    const uint32_t p0 = nf ? bpos.front() : 0u;
     g->b_file_idx.resize(nf); g->b_status.resize(nf); g->b_n_rows.resize(nf); g->b_n_sites.resize(nf);
     g->b_key_rows.assign((size_t)nf * nk, 0u);
     g->b_unit_file.clear(); g->b_unit_key.clear(); g->b_unit_rows.clear(); g->b_ridx.clear(); g->b_descs.clear();
     bool regular = true;
     uint64_t packed = 0, n_segs = 0;
     for (uint32_t b = 0; b < nf; ++b) {
-      const pfa::FileRec& f = g->files[p0 + b];
-      g->b_file_idx[b] = g->feed[p0 + b];
+      const pfa::FileRec& f = g->files[bpos[b]];
+      g->b_file_idx[b] = g->feed[bpos[b]];
       g->b_status[b] = f.status;
       g->b_n_rows[b] = f.n_rows;
       g->b_n_sites[b] = f.n_sites;
@@ -739,7 +820,7 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
     const uint8_t* const text_base = uv.front().big ? uv.front().d : g->d_text;
     uint64_t si = 0;
     for (uint32_t b = 0; b < nf; ++b) {
-      const pfa::FileRec& f = g->files[p0 + b];
+      const pfa::FileRec& f = g->files[bpos[b]];
       if (f.status != 0) continue;
       const uint64_t stride = std::max<uint64_t>(16, ((uint64_t)f.n_sites + g->stride_align - 1) & ~uint64_t(g->stride_align - 1));
       if (stride > 0xFFFFFFF0ull) { pfa::set_error("pfa_ingest_next: %s: sequences too long", g->paths[g->b_file_idx[b]].c_str()); return PFA_ERR_ARG; }
@@ -747,7 +828,9 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
       packed += pfa::up256((size_t)(std::max<uint64_t>(f.n_rows, 1) * stride));
       if (f.n_sites) {
         const uint64_t use_off = (uint64_t)(uv[f.use - lo].d - text_base);
-        for (uint32_t r = 0; r < f.n_rows; ++r) h_segs[si++] = pfa::Seg{use_off + f.row_off[r], base + (uint64_t)r * stride, f.n_sites, b};
+        for (uint32_t r = 0; r < f.n_rows; ++r)
+          h_segs[si++] = pfa::Seg{use_off + (f.row_off[r] & ~pfa::kRowPacked), base + (uint64_t)r * stride, f.n_sites,
+                                  b | ((f.row_off[r] & pfa::kRowPacked) ? pfa::kSegPacked : 0u)};
       }
       pfa_desc d{};
       d.base_off = base;
@@ -826,13 +909,14 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
         g->uses[u].repack_ev = bev;
         if (g->uses[u].big) g->big_dev.push_back(g->uses[u].d);
         // the rows of these files are on their way: their tables can go
-        for (uint32_t p = g->uses[u].first_pos; p < g->uses[u].first_pos + g->uses[u].n_pos; ++p) {
+        for (uint32_t p : g->uses[u].pos) {
           pfa::FileRec& f = g->files[p];
           std::vector<uint64_t>().swap(f.row_off);
           std::vector<uint32_t>().swap(f.key_rows);
         }
       }
       g->consumed = hi;
+      g->n_handed += nf;
       g->cv_consumed.notify_all();
     }
     g->n_batches += 1;
@@ -873,7 +957,7 @@ int pfa_ingest_stats(const pfa_ingest* g, double* out8) {
   out8[3] = (double)g->ns_copy.load() * 1e-9;
   out8[4] = (double)g->bytes_copied.load();
   out8[5] = (double)g->want_threads;
-  out8[6] = (double)g->ns_main.load() * 1e-9;
+  out8[6] = (double)g->ns_wait.load() * 1e-9;
   out8[7] = (double)g->n_batches;
   return PFA_OK;
 }
@@ -883,7 +967,7 @@ void pfa_ingest_close(pfa_ingest* g) {
   {
     std::lock_guard<std::mutex> lk(g->mu);
     g->stop = true;
-    g->cv_work.notify_all(); g->cv_turn.notify_all(); g->cv_slot.notify_all();
+    g->cv_work.notify_all(); g->cv_slot.notify_all(); g->cv_open.notify_all();
     g->cv_up.notify_all(); g->cv_batch.notify_all(); g->cv_consumed.notify_all();
   }
   for (std::thread& t : g->workers) if (t.joinable()) t.join();
@@ -896,11 +980,9 @@ void pfa_ingest_close(pfa_ingest* g) {
   }
   for (pfa::Use& u : g->uses) {
     if (u.ev) (void)hipEventDestroy(u.ev);
-    if (u.big) {   // oversized files that never reached a batch
+    if (u.big) {   // oversized files that never reached a batch, or whose copy was never waited for
       if (!u.consumed) (void)hipFree(u.d);
-      bool given = false;
-      for (pfa::Pinned& p : g->big_pinned_done) given = given || p.h == u.h;
-      if (!given && u.h) g->big_pinned_done.push_back(pfa::Pinned{u.h, u.cap});
+      if (u.h) { g->big_pinned_done.push_back(pfa::Pinned{u.h, u.cap}); u.h = nullptr; }
     }
   }
   for (hipEvent_t e : g->ev_pool) (void)hipEventDestroy(e);

@@ -159,7 +159,7 @@ class Ingest:
         buf = (ctypes.c_double * 8)()
         _lib.check(_lib.load().pfa_ingest_stats(self.handle, buf))
         return {"read_thread_s": buf[0], "index_thread_s": buf[1], "bytes_read": int(buf[2]), "copy_busy_s": buf[3],
-                "bytes_copied": int(buf[4]), "loader_threads": int(buf[5]), "repack_plan_s": buf[6], "batches": int(buf[7])}
+                "bytes_copied": int(buf[4]), "loader_threads": int(buf[5]), "turn_wait_thread_s": buf[6], "batches": int(buf[7])}
 
     def close(self):
         if self.handle is not None and self.handle.value:
