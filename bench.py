@@ -56,7 +56,7 @@ def parse(argv=None):
     ap.add_argument("--legs", default="small_launches,workloads,end_to_end,cold_start",
                     help="which extra legs of the default run to take (comma-separated)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
-    ap.add_argument("--e2e-files", type=int, default=8192, help="FASTA files of the plain end-to-end leg (the coding / --pops legs use half as many)")
+    ap.add_argument("--e2e-files", type=int, default=16384, help="FASTA files per end-to-end directory (halved until tmpfs has room)")
     ap.add_argument("--e2e-files-per-rank", type=int, default=4096, help="files per rank of the N > 1 end-to-end leg (weak scaling)")
     ap.add_argument("--e2e-reps", type=int, default=5, help="warm runs per end-to-end mode (best and median are reported)")
     return ap.parse_args(argv)
@@ -204,33 +204,45 @@ def end_to_end(args):
     from polyfasta_amd import _lib, cli, scan, synth
     lib = _lib.load()
     N = 50
-    M1, M2 = args.e2e_files, max(args.e2e_files // 2, 1)
-    need = int(1.1 * N * (M1 * 10010 + M2 * 9010))
-    roots = [r for r in ("/dev/shm", tempfile.gettempdir()) if os.path.isdir(r) and shutil.disk_usage(r).free > 2 * need]
-    if not roots:
-        return {"skipped": f"no scratch directory with {2 * need >> 20} MiB free for {M1 + M2} FASTA files"}
-    root = tempfile.mkdtemp(prefix="pfa_e2e_", dir=roots[0])
+    # as many files as tmpfs has room for (the start-up of a run — argparse, listdir, sorted, the path table: ~9 ms — is a fixed
+    # cost; BASELINE configs[4] is a 100 000-file directory), the same number for both directories
+    root0 = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    M1 = 0
+    for m in (args.e2e_files, args.e2e_files // 2, args.e2e_files // 4, args.e2e_files // 8):
+        if m >= 64 and shutil.disk_usage(root0).free > 1.5 * 1.05 * N * m * (10010 + 9010):
+            M1 = m
+            break
+    if not M1:
+        return {"skipped": f"{root0} has no room for {args.e2e_files // 8} + {args.e2e_files // 8} FASTA files"}
+    M2 = M1
+    root = tempfile.mkdtemp(prefix="pfa_e2e_", dir=root0)
     out = os.path.join(tempfile.gettempdir(), f"pfa_e2e_out_{os.getpid()}.csv")
     report = {"command": "python -m polyfasta_amd -d DIR -o out.csv -s [mode flags] (in-process, page-cached files in tmpfs; warm = the "
                          "pinned ring and the device buffers of the process exist, as for every batch after a job's first)",
               "target_alignments_per_s": 10000, "pcie_h2d_peak_GBps_measured": 57.5}
     try:
         def write_dir(name, M, L, coding, pops):
+            """M files of N x L in a fresh directory, generated 2 048 at a time; returns the directory and the first 48 matrices"""
             d = os.path.join(root, name)
             os.makedirs(d)
             p = synth.make_params(N, args.theta)
             stride = scan.row_stride_for(L, 128)
-            sp = _lib.SynthParamsC(seed=7, first_aln=0, n_aln=M, n_rows=N, n_sites=L, row_stride=stride, seg_thresh=p.seg_thresh,
-                                   tri_thresh=p.tri_thresh, n_units=len(p.units), coding=int(coding))
-            bases = np.zeros(M * N * stride, dtype=np.uint8)
-            _lib.check(lib.pfa_synth_fill_host(_lib.ptr(bases), ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(p.cdf)),
-                                               _lib.ptr(np.ascontiguousarray(p.units))))
             hdr = [f">{h}\n".encode() for h in synth.headers_for(N, pops)]
-            for m in range(M):
-                mat = bases[m * N * stride:(m + 1) * N * stride].reshape(N, stride)[:, :L]
-                with open(os.path.join(d, f"aln{m:06d}.fa"), "wb") as fh:
-                    fh.write(b"".join(h + mat[i].tobytes() + b"\n" for i, h in enumerate(hdr)))
-            return d, bases.reshape(M, N, stride)[:, :, :L]
+            keep = None
+            for m0 in range(0, M, 2048):
+                mc = min(2048, M - m0)
+                sp = _lib.SynthParamsC(seed=7, first_aln=m0, n_aln=mc, n_rows=N, n_sites=L, row_stride=stride, seg_thresh=p.seg_thresh,
+                                       tri_thresh=p.tri_thresh, n_units=len(p.units), coding=int(coding))
+                bases = np.zeros(mc * N * stride, dtype=np.uint8)
+                _lib.check(lib.pfa_synth_fill_host(_lib.ptr(bases), ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(p.cdf)),
+                                                   _lib.ptr(np.ascontiguousarray(p.units))))
+                for m in range(mc):
+                    mat = bases[m * N * stride:(m + 1) * N * stride].reshape(N, stride)[:, :L]
+                    with open(os.path.join(d, f"aln{m0 + m:06d}.fa"), "wb") as fh:
+                        fh.write(b"".join(h + mat[i].tobytes() + b"\n" for i, h in enumerate(hdr)))
+                if keep is None:
+                    keep = bases.reshape(mc, N, stride)[:48, :, :L].copy()
+            return d, keep
 
         t0 = time.perf_counter()
         d1, b1 = write_dir("plain", M1, 10000, False, 0)

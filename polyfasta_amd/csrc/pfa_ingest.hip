@@ -609,9 +609,12 @@ uint32_t auto_threads() {
   cpu_set_t set;
   uint32_t cpus = 1;
   if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = (uint32_t)std::max(1, CPU_COUNT(&set));
+  // the CPUs this process may use, shared with the other ranks of the node — unless the rank has already bound itself to
+  // its own share of them (dist.bind_to_gpu_node sets PFA_CPUS_ARE_MINE)
   uint32_t local = 1;
-  for (const char* var : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
-    if (const char* e = getenv(var)) { const long v = strtol(e, nullptr, 10); if (v > 0) { local = (uint32_t)v; break; } }
+  if (!getenv("PFA_CPUS_ARE_MINE"))
+    for (const char* var : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
+      if (const char* e = getenv(var)) { const long v = strtol(e, nullptr, 10); if (v > 0) { local = (uint32_t)v; break; } }
   return std::max(1u, std::min(16u, cpus / std::max(local, 1u)));
 }
 

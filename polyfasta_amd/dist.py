@@ -198,6 +198,8 @@ def bind_to_gpu_node(local_rank: int, local_world: int = 1, **roots):
     switches it off.  Returns the CPU list it bound to, or None."""
     if os.environ.get("PFA_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
         return None
+    if os.environ.get("PFA_CPUS_ARE_MINE") and not roots:      # bound already (a process binds once)
+        return sorted(os.sched_getaffinity(0))
     mine = gpu_local_cpus(local_rank, **roots)
     if not mine:
         return None
@@ -212,6 +214,7 @@ def bind_to_gpu_node(local_rank: int, local_world: int = 1, **roots):
         os.sched_setaffinity(0, share)
     except OSError:
         return None
+    os.environ["PFA_CPUS_ARE_MINE"] = "1"     # the ingest sizes its loader pool from this rank's own CPUs (no further split by ranks)
     return share
 
 

@@ -232,8 +232,10 @@ def test_rank_binds_to_the_cpus_next_to_its_gpu(tmp_path, monkeypatch):
         got = dist.bind_to_gpu_node(1, 4, **roots)       # GPUs 0 and 1 share node 0: rank 1 takes its second half
         share = lists[0][len(lists[0]) // 2:] or lists[0]
         assert got == share and sorted(os.sched_getaffinity(0)) == share
+        assert os.environ.get("PFA_CPUS_ARE_MINE") == "1"      # the loader pool is sized from this share, not split again
     finally:
         os.sched_setaffinity(0, before)
+        os.environ.pop("PFA_CPUS_ARE_MINE", None)
     assert dist.bind_to_gpu_node(0, 1, kfd_root=str(tmp_path / "nope"), pci_root=str(pci)) is None
     assert os.sched_getaffinity(0) == before
     monkeypatch.setenv("PFA_NO_AFFINITY", "1")
