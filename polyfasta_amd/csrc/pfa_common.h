@@ -1,7 +1,11 @@
 // pfa_common.h — context, error plumbing and small helpers shared by the
 // translation units of libpfa_hip.so.
 #pragma once
+#ifdef PFA_INGEST_HOST_TEST
+#include "hip_mock.h"   // tests/: the HIP runtime as threads and memcpy, for the CPU sanitizer build of the ingest
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 #include <stdio.h>
 

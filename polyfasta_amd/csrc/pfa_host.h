@@ -13,6 +13,16 @@ namespace pfa {
 
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
+// one record's sequence run: `len` raw bytes at text + src -> packed + dst, upper-cased, the rest
+// of the row (up to its stride) zeroed
+struct Seg {
+  unsigned long long src;
+  unsigned long long dst;
+  uint32_t len;
+  uint32_t file;   // index into the batch's `bad` words | kSegPacked: the run is 2 bits per base
+};
+static constexpr uint32_t kSegPacked = 0x80000000u;
+
 // per-thread scratch of index_compact(), reused from file to file
 struct IndexScratch {
   struct Span { uint64_t first_line, end; uint32_t n_lines; };

@@ -44,16 +44,11 @@
 
 namespace pfa {
 
-// one record's sequence run: `len` raw bytes at text + src -> packed + dst, upper-cased, the rest
-// of the row (up to its stride) zeroed
-struct Seg {
-  unsigned long long src;
-  unsigned long long dst;
-  uint32_t len;
-  uint32_t file;   // index into the batch's `bad` words | kSegPacked: the run is 2 bits per base
-};
-static constexpr uint32_t kSegPacked = 0x80000000u;
-
+#ifdef PFA_INGEST_HOST_TEST
+// CPU sanitizer build of the pipeline (tests/ingest_tsan.cpp, with tests/hip_mock.h in place of the HIP runtime):
+// the harness supplies a host double of the repack launch
+int launch_repack(const uint8_t* text, const Seg* segs, uint32_t n_segs, uint8_t* packed, uint32_t stride_align, uint32_t* bad, hipStream_t st);
+#else
 __device__ inline uint32_t swar_upper(uint32_t w) {
   const uint32_t h = w & 0x7F7F7F7Fu;
   const uint32_t ge_a = h + 0x1F1F1F1Fu;   // bit 7 of a byte: its low seven bits >= 'a'
@@ -130,6 +125,13 @@ __global__ void __launch_bounds__(256) repack_kernel(const uint8_t* __restrict__
     if (seen & 0x80808080u) bad[g.file] = 1u;   // (kSegPacked is clear here)
   }
 }
+
+static int launch_repack(const uint8_t* text, const Seg* segs, uint32_t n_segs, uint8_t* packed, uint32_t stride_align, uint32_t* bad, hipStream_t st) {
+  hipLaunchKernelGGL(repack_kernel, dim3(n_segs < (1u << 20) ? n_segs : (1u << 20)), dim3(256), 0, st, text, segs, n_segs, packed, stride_align, bad);
+  PFA_HIP(hipGetLastError());
+  return PFA_OK;
+}
+#endif
 
 namespace {
 
@@ -316,6 +318,9 @@ int new_use(pfa_ingest* g, std::unique_lock<std::mutex>& lk, size_t need, uint32
     const size_t remaining = g->feed.size() - pos;
     size_t est = need * std::max<size_t>(remaining, 1);
     est = (est + kMinSlot - 1) / kMinSlot * kMinSlot;
+    // (the first file to arrive may be the smallest of a directory — an empty or rejected one even: unless the job is a
+    // handful of files, slots are not sized below 4 MiB; they are allocated one by one as they come into use)
+    if (remaining > 8) est = std::max(est, size_t(4) << 20);
     g->slot_bytes = std::min(std::max(est, kMinSlot), g->max_slot);
     const size_t want = (size_t)g->n_dev_slots * g->slot_bytes + 256u;
     {
@@ -893,10 +898,9 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
       uint32_t* d_bad = nullptr;
       PFA_HIP(hipHostGetDevicePointer((void**)&d_bad, g->bad_words, 0));
       PFA_HIP(hipMemcpyAsync(pfa::g_cache.d_segs, h_segs, seg_bytes, hipMemcpyHostToDevice, st));
-      const unsigned blocks = (unsigned)std::min<uint64_t>(n_segs, 1u << 20);
-      hipLaunchKernelGGL(pfa::repack_kernel, dim3(blocks), dim3(256), 0, st, text_base, reinterpret_cast<const pfa::Seg*>(pfa::g_cache.d_segs),
-                         (uint32_t)std::min<uint64_t>(n_segs, 0xFFFFFFFFull), pfa::g_cache.d_packed, g->stride_align, d_bad);
-      PFA_HIP(hipGetLastError());
+      rc = pfa::launch_repack(text_base, reinterpret_cast<const pfa::Seg*>(pfa::g_cache.d_segs), (uint32_t)std::min<uint64_t>(n_segs, 0xFFFFFFFFull),
+                              pfa::g_cache.d_packed, g->stride_align, d_bad, st);
+      if (rc != PFA_OK) return rc;
     }
     hipEvent_t& bev = g->batch_ev[g->n_batches % pfa::kBatchEvents];
     if (!bev) PFA_HIP(hipEventCreateWithFlags(&bev, hipEventDisableTiming));
