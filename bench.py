@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--e2e-files", type=int, default=16384, help="FASTA files per end-to-end directory (halved until tmpfs has room)")
     ap.add_argument("--e2e-files-per-rank", type=int, default=4096, help="files per rank of the N > 1 end-to-end leg (weak scaling)")
+    ap.add_argument("--e2e-ranks-timeout", type=float, default=240.0, help="watchdog of the N > 1 end-to-end leg (seconds)")
     ap.add_argument("--e2e-reps", type=int, default=5, help="warm runs per end-to-end mode (best and median are reported)")
     return ap.parse_args(argv)
 
@@ -308,6 +309,13 @@ def end_to_end(args):
             os.unlink(out)
 
 
+def e2e_ranks_paths():
+    """(tmpfs directory, CSV file) of the N > 1 end-to-end leg: names every rank of one launcher derives alike"""
+    import tempfile
+    root = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir(), f"pfa_e2e_ranks_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+    return root, os.path.join(tempfile.gettempdir(), f"pfa_e2e_ranks_out_{os.getppid()}.csv")
+
+
 def end_to_end_ranks(args, comm, rank, world):
     """The thing north_star shards, measured: `--dir` through the shared work queue on `world` ranks.  Every rank
     writes its share of one tmpfs directory (N = 50 x 10 kb files, `--e2e-files-per-rank` per rank: weak scaling),
@@ -324,8 +332,7 @@ def end_to_end_ranks(args, comm, rank, world):
     N, L = 50, 10000
     per = args.e2e_files_per_rank
     M = per * world
-    root = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir(), f"pfa_e2e_ranks_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
-    out = os.path.join(tempfile.gettempdir(), f"pfa_e2e_ranks_out_{os.getppid()}.csv")
+    root, out = e2e_ranks_paths()
     p = synth.make_params(N, args.theta)
     stride = scan.row_stride_for(L, 128)
     try:
@@ -583,17 +590,11 @@ def main():
     if comm is not None:
         dt = comm.max_float(dt)
 
-    e2e_ranks = None
-    if world > 1 and comm is not None and not args.no_extras and "end_to_end" in args.legs.split(","):
-        try:
-            e2e_ranks = end_to_end_ranks(args, comm, rank, world)
-        except Exception as e:              # noqa: BLE001   (every rank takes the same path: the barriers inside stay matched)
-            e2e_ranks = {"error": f"{type(e).__name__}: {e}"}
-
     kms = plan.kernel_ms(args.steps)
     k_avg_ms = float(kms.mean()) if len(kms) else float("nan")
     achieved = hw.alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
 
+    line = None
     if rank == 0:
         res = out.results
         N, L, B, K = hw.N, hw.L, hw.B, hw.K
@@ -635,8 +636,33 @@ def main():
             # such a line is not a multi-GPU measurement, and says so
             line["rehearsal"] = {"shared_gpu": bool(os.environ.get("PFA_ALLOW_SHARED_GPU")), "comm": type(comm).__name__,
                                  "note": "n_gpus counts ranks, not devices: not a scaling measurement"}
-        if e2e_ranks is not None:
+    if world > 1 and comm is not None and not args.no_extras and "end_to_end" in args.legs.split(","):
+        # The N > 1 end-to-end leg is a collective affair (shared queue, barriers, one gather): if a rank failed inside it the
+        # others would wait for ever and the headline measured above would never be printed.  A watchdog per rank prints the
+        # line without the leg and ends the process cleanly when the leg has not come back in time.
+        import threading
+
+        def bail():
+            if rank == 0:
+                import shutil
+                shutil.rmtree(e2e_ranks_paths()[0], ignore_errors=True)      # gigabytes of tmpfs: not left behind
+                line["end_to_end"] = {"error": f"the N > 1 end-to-end leg did not finish within {args.e2e_ranks_timeout} s"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(args.e2e_ranks_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            e2e_ranks = end_to_end_ranks(args, comm, rank, world)
+        except Exception as e:              # noqa: BLE001   (the other ranks may be waiting at a barrier: let the watchdog end the job)
+            e2e_ranks = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                line["end_to_end"] = e2e_ranks
+            dog.join()
+        dog.cancel()
+        if rank == 0:
             line["end_to_end"] = e2e_ranks
+    if rank == 0:
         extras = world == 1 and comm is None and not args.no_extras and default_shape
         if extras and not args.no_cpu_baseline:
             try:

@@ -157,3 +157,21 @@ def test_bench_with_two_ranks_on_one_gpu(gpu):
     e = j["end_to_end"]
     assert e["ranks"] == 2 and e["files"] == 192 and e["rows_ok"] is True and e["alignments_per_s"] > 0, e
     assert j["rehearsal"]["shared_gpu"] is True
+
+
+def test_bench_prints_its_line_when_the_multi_rank_end_to_end_leg_hangs(gpu):
+    """The N > 1 end-to-end leg runs under a watchdog: when it does not come back (here: a 50 ms allowance), rank 0
+    still prints the ONE JSON line with the headline it measured before, the leg reported as an error, every rank
+    exits 0."""
+    import json
+    env = dict(os.environ, PFA_ALLOW_SHARED_GPU="1", PFA_COMM_FACTORY="tests._gloo_comm:GlooComm", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "512",
+                        "--e2e-files-per-rank", "512", "--e2e-reps", "2", "--e2e-ranks-timeout", "0.05"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "did not finish" in j["end_to_end"]["error"]
+    import glob
+    assert not glob.glob("/dev/shm/pfa_e2e_ranks_*"), "the leg's tmpfs directory was left behind"
