@@ -415,6 +415,13 @@ typedef struct pfa_ingest_batch {
 /* `paths`: every file the job may read (kept: names for the rows).  Nothing is read
  * before pfa_ingest_feed(). */
 int pfa_ingest_open(const char* const* paths, uint32_t n_files, const pfa_ingest_opts* opts, pfa_ingest** out);
+/* The reference's --dir listing done here (PolyFastA.py:93-94, :104): every entry of `dir` except "." and ".." as
+ * "dir/name", sorted as Python sorts those strings (for UTF-8 names byte order is code-point order).
+ * PFA_ERR_UNSUPPORTED when a name is not UTF-8 (the caller lists and sorts itself), PFA_ERR_IO when the
+ * directory cannot be opened. */
+int pfa_ingest_open_dir(const char* dir, const pfa_ingest_opts* opts, pfa_ingest** out, uint32_t* n_files);
+/* path i of the ingest (owned by it) */
+const char* pfa_ingest_path(const pfa_ingest* ing, uint32_t i);
 /* append files (indices into `paths`; NULL = 0..n-1) to the feed order; `last` != 0: no
  * further feed follows (a multi-GPU rank feeds what it claims from the shared queue) */
 int pfa_ingest_feed(pfa_ingest* ing, const uint32_t* file_idx, uint32_t n, int last);

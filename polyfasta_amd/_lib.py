@@ -147,6 +147,8 @@ _PROTOTYPES = {
     "pfa_fasta_index_compact": (ctypes.c_int64, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint64]),
     "pfa_fasta_pack2": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp]),
     "pfa_ingest_open": (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, ctypes.POINTER(IngestOptsC), ctypes.POINTER(_vp)]),
+    "pfa_ingest_open_dir": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(IngestOptsC), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint32)]),
+    "pfa_ingest_path": (ctypes.c_char_p, [_vp, ctypes.c_uint32]),
     "pfa_ingest_feed": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_int]),
     "pfa_ingest_backlog": (ctypes.c_uint32, [_vp]),
     "pfa_ingest_next": (ctypes.c_int, [_vp, ctypes.POINTER(IngestBatchC)]),

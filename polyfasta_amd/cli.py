@@ -540,15 +540,28 @@ startup_marks = []  # (phase that ENDS here, wall clock): __main__ and main() ap
 last_stats = {}     # what the last run_files() measured (bench.py `end_to_end`: the stage breakdown)
 
 
-def run_files(paths, args, sink, rank, world, comm, wq, keys):
-    """The file loop (PolyFastA.py:104-140) on the streaming ingest.  One rank: rows leave batch by
+def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
+    """`paths`: the sorted file list — or None with `directory`: the library lists and sorts it itself
+    (PolyFastA.py:93-94, :104; falls back to os.listdir where it declines).
+    The file loop (PolyFastA.py:104-140) on the streaming ingest.  One rank: rows leave batch by
     batch while later files are still being read.  Several ranks: every rank drains the shared
     queue, the blocks travel to rank 0 once (`comm.gather_bytes`), rank 0 orders and writes them."""
     import time
     from . import ingest
     trace = [] if os.environ.get("PFA_TRACE") else None      # per-batch timeline on stderr (tools/e2e_modes_probe.py)
     t00 = time.perf_counter()
-    ing = ingest.Ingest(paths, keys=keys, cds=args.cds)
+    ing = None
+    if paths is None:
+        ing = ingest.Ingest.from_dir(directory, keys=keys, cds=args.cds)
+        if ing is None:                      # a name that is not UTF-8, or a directory that cannot be listed: the reference's own way
+            paths = sorted(directory + "/" + i for i in os.listdir(directory))
+        else:
+            paths = ing.paths
+    if ing is None:
+        ing = ingest.Ingest(paths, keys=keys, cds=args.cds)
+    # the ranks of a node share the file loop through a work queue (claim order = path order, the same on every rank)
+    from . import dist
+    wq = dist.WorkQueue(len(paths), world) if world > 1 else None
     t_open = time.perf_counter() - t00
     if trace is not None:
         trace.append(("open", time.perf_counter() - t00, len(paths)))
@@ -603,6 +616,8 @@ def run_files(paths, args, sink, rank, world, comm, wq, keys):
                 emit_block(allb, sink, args, ing.table, paths, keys)
         if trace is not None:
             trace.append(("loop_end", time.perf_counter() - t00))
+        if comm is not None:
+            comm.barrier()
         t4 = time.perf_counter()
         sink.flush()
         st = ing.stats()
@@ -616,6 +631,8 @@ def run_files(paths, args, sink, rank, world, comm, wq, keys):
         return st
     finally:
         t9 = time.perf_counter()
+        if wq is not None:
+            wq.close(unlink=rank == 0)       # (success: every rank is past its last claim, the barrier above; failure: the others keep their descriptor)
         ing.close()
         if trace is not None:
             print("PFA_TRACE close", round(time.perf_counter() - t9, 5), file=sys.stderr)
@@ -642,8 +659,12 @@ def main(argv=None, comm=None, close_comm=True):
     if comm is None and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # one process per GPU: start them now, before anything here has touched the GPU or the files
         return dist.spawn_ranks(args.gpus, [sys.executable, "-m", "polyfasta_amd"] + list(sys.argv[1:] if argv is None else argv))
-    if len(args.file) == 0 and args.dir != ".":                                    # :93-94
+    dir_mode = len(args.file) == 0 and args.dir != "."                             # :93-94: every entry of the directory,
+    if dir_mode and args.pipe:                                                     #   (with --pipe the listing only serves the error of :105-106)
         args.file = [args.dir + "/" + i for i in os.listdir(args.dir)]
+        dir_mode = False
+    if dir_mode:                                                                   #   listed and sorted by the library (run_files)
+        pass
     elif len(args.file) == 0 and args.dir == "." and args.pipe:                    # :96-100
         args.file = ["stdin"] if not args.name else [args.name]
     if len(args.file) > 0 and args.pipe and not (args.file[0] == "stdin" or args.file[0] == args.name):
@@ -676,7 +697,7 @@ def main(argv=None, comm=None, close_comm=True):
     sink = Sink(args.out, args.silent)
     if rank == 0:
         sink.header(args.cds, args.sfs)                                            # :102-103
-    paths = sorted(args.file)                                                      # :104
+    paths = None if dir_mode and not args.pipe else sorted(args.file)              # :104
     keys = args.pops.split(",") if args.pops else []                               # :123
     if args.pipe:
         events = process_pipe([(0, paths[0])] if rank == 0 and paths else [], args)
@@ -685,18 +706,11 @@ def main(argv=None, comm=None, close_comm=True):
         if rank == 0:
             emit(events, sink, args.cds, args.jc, args.sfs)
     else:
-        wq = dist.WorkQueue(len(paths), world) if world > 1 else None            # the ranks of the node share the file loop
         if os.environ.get("PFA_TRACE"):
             print("PFA_TRACE before_run_files", round(time.perf_counter() - t_main, 5), file=sys.stderr)
-        try:
-            run_files(paths, args, sink, rank, world, comm, wq, keys)
-            if os.environ.get("PFA_TRACE"):
-                print("PFA_TRACE after_run_files", round(time.perf_counter() - t_main, 5), file=sys.stderr)
-            if comm is not None:
-                comm.barrier()
-        finally:
-            if wq is not None:
-                wq.close(unlink=rank == 0)       # every rank is past its last claim: the barrier above
+        run_files(paths, args, sink, rank, world, comm, keys, directory=args.dir if dir_mode else None)
+        if os.environ.get("PFA_TRACE"):
+            print("PFA_TRACE after_run_files", round(time.perf_counter() - t_main, 5), file=sys.stderr)
     mark("files -> rows (ingest, first kernel launches, fetch, print)")
     if rank == 0 and len(args.out) != 0 and not args.silent:                       # :141-142
         print("")

@@ -22,6 +22,7 @@
 // The rows of a record reach the card as (offset, length, form) triples; expansion of packed rows,
 // upper-casing of the others and the test for bytes >= 0x80 (outside the one-byte-per-base contract)
 // happen in repack_kernel, which writes every byte of the matrices anyway.  Nothing here scans on the CPU.
+#include <dirent.h>
 #include <fcntl.h>
 #include <sched.h>
 #include <string.h>
@@ -616,10 +617,12 @@ uint32_t auto_threads() {
   if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = (uint32_t)std::max(1, CPU_COUNT(&set));
   // the CPUs this process may use, shared with the other ranks of the node — unless the rank has already bound itself to
   // its own share of them (dist.bind_to_gpu_node sets PFA_CPUS_ARE_MINE)
-  uint32_t local = 1;
-  if (!getenv("PFA_CPUS_ARE_MINE"))
-    for (const char* var : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
-      if (const char* e = getenv(var)) { const long v = strtol(e, nullptr, 10); if (v > 0) { local = (uint32_t)v; break; } }
+  uint32_t local = 1, ranks = 1;
+  for (const char* var : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
+    if (const char* e = getenv(var)) { const long v = strtol(e, nullptr, 10); if (v > 0) { ranks = (uint32_t)v; break; } }
+  if (!getenv("PFA_CPUS_ARE_MINE")) local = ranks;
+  // measured (profiles/r03_e2e_thread_sweep.txt): 16 loaders 200-214 k alignments/s best / 176-204 k median; 20-24 reach 220 k in
+  // their best runs but swing down to 120-150 k on the same box; 28 and more collapse
   return std::max(1u, std::min(16u, cpus / std::max(local, 1u)));
 }
 
@@ -639,10 +642,7 @@ int ensure_dev(uint8_t** p, size_t* cap, size_t need) {
 
 extern "C" {
 
-int pfa_ingest_open(const char* const* paths, uint32_t n_files, const pfa_ingest_opts* opts, pfa_ingest** out) {
-  PFA_NEED_INIT();
-  if (!out || (n_files && !paths)) { pfa::set_error("pfa_ingest_open: NULL argument"); return PFA_ERR_ARG; }
-  *out = nullptr;
+static int ingest_open_impl(std::vector<std::string>&& paths, const pfa_ingest_opts* opts, pfa_ingest** out) {
   pfa_ingest_opts o{};
   if (opts) o = *opts;
   if (o.stride_align == 0) o.stride_align = 128;
@@ -652,13 +652,10 @@ int pfa_ingest_open(const char* const* paths, uint32_t n_files, const pfa_ingest
   pfa_ingest* g = nullptr;
   try {
     g = new pfa_ingest();
-    g->paths.reserve(n_files);
-    g->names_off.reserve((size_t)n_files + 1);
+    g->paths = std::move(paths);
+    g->names_off.reserve(g->paths.size() + 1);
     g->names_off.push_back(0);
-    for (uint32_t i = 0; i < n_files; ++i) {
-      if (!paths[i]) { delete g; pfa::set_error("pfa_ingest_open: path %u is NULL", i); return PFA_ERR_ARG; }
-      g->paths.emplace_back(paths[i]);
-      const std::string& p = g->paths.back();
+    for (const std::string& p : g->paths) {
       const size_t sl = p.rfind('/');                        // display name = text after the last '/' (PolyFastA.py:110)
       g->names_blob.append(p, sl == std::string::npos ? 0 : sl + 1, std::string::npos);
       g->names_off.push_back(g->names_blob.size());
@@ -695,6 +692,81 @@ int pfa_ingest_open(const char* const* paths, uint32_t n_files, const pfa_ingest
   *out = g;
   return PFA_OK;
 }
+
+int pfa_ingest_open(const char* const* paths, uint32_t n_files, const pfa_ingest_opts* opts, pfa_ingest** out) {
+  PFA_NEED_INIT();
+  if (!out || (n_files && !paths)) { pfa::set_error("pfa_ingest_open: NULL argument"); return PFA_ERR_ARG; }
+  *out = nullptr;
+  try {
+    std::vector<std::string> v;
+    v.reserve(n_files);
+    for (uint32_t i = 0; i < n_files; ++i) {
+      if (!paths[i]) { pfa::set_error("pfa_ingest_open: path %u is NULL", i); return PFA_ERR_ARG; }
+      v.emplace_back(paths[i]);
+    }
+    return ingest_open_impl(std::move(v), opts, out);
+  } catch (const std::bad_alloc&) {
+    pfa::set_error("pfa_ingest_open: out of host memory");
+    return PFA_ERR_NOMEM;
+  }
+}
+
+// well-formed UTF-8 (no overlong forms, no surrogates, <= U+10FFFF): for such names byte order is code-point order
+static bool valid_utf8(const char* s) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(s);
+  while (*p) {
+    if (*p < 0x80) { ++p; continue; }
+    uint32_t n, cp, lo;
+    if ((*p & 0xE0) == 0xC0) { n = 1; cp = *p & 0x1Fu; lo = 0x80; }
+    else if ((*p & 0xF0) == 0xE0) { n = 2; cp = *p & 0x0Fu; lo = 0x800; }
+    else if ((*p & 0xF8) == 0xF0) { n = 3; cp = *p & 0x07u; lo = 0x10000; }
+    else return false;
+    ++p;
+    for (uint32_t k = 0; k < n; ++k, ++p) {
+      if ((*p & 0xC0) != 0x80) return false;
+      cp = cp << 6 | (*p & 0x3Fu);
+    }
+    if (cp < lo || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+  }
+  return true;
+}
+
+int pfa_ingest_open_dir(const char* dir, const pfa_ingest_opts* opts, pfa_ingest** out, uint32_t* n_files) {
+  PFA_NEED_INIT();
+  if (!dir || !out || !n_files) { pfa::set_error("pfa_ingest_open_dir: NULL argument"); return PFA_ERR_ARG; }
+  *out = nullptr;
+  *n_files = 0;
+  try {
+    DIR* dp = opendir(dir);
+    if (!dp) { pfa::set_error("pfa_ingest_open_dir: cannot open %s", dir); return PFA_ERR_IO; }
+    std::vector<std::string> names;
+    bool utf8 = valid_utf8(dir);
+    while (dirent* e = readdir(dp)) {
+      const char* n = e->d_name;
+      if (n[0] == '.' && (n[1] == 0 || (n[1] == '.' && n[2] == 0))) continue;     // os.listdir leaves "." and ".." out, nothing else
+      utf8 = utf8 && valid_utf8(n);
+      names.emplace_back(n);
+    }
+    closedir(dp);
+    if (!utf8) {   // Python would sort the escaped bytes by code point (U+DC80..): leave such directories to the caller
+      pfa::set_error("pfa_ingest_open_dir: a name in %s is not UTF-8", dir);
+      return PFA_ERR_UNSUPPORTED;
+    }
+    if (names.size() > 0xFFFFFFF0ull) { pfa::set_error("pfa_ingest_open_dir: too many entries"); return PFA_ERR_ARG; }
+    std::sort(names.begin(), names.end());                   // sorted(dir + "/" + name): the common prefix drops out (PolyFastA.py:94, :104)
+    const std::string prefix = std::string(dir) + "/";
+    for (std::string& n : names) n.insert(0, prefix);
+    const uint32_t n = (uint32_t)names.size();
+    const int rc = ingest_open_impl(std::move(names), opts, out);
+    if (rc == PFA_OK) *n_files = n;
+    return rc;
+  } catch (const std::bad_alloc&) {
+    pfa::set_error("pfa_ingest_open_dir: out of host memory");
+    return PFA_ERR_NOMEM;
+  }
+}
+
+const char* pfa_ingest_path(const pfa_ingest* g, uint32_t i) { return g && i < g->paths.size() ? g->paths[i].c_str() : nullptr; }
 
 int pfa_ingest_feed(pfa_ingest* g, const uint32_t* file_idx, uint32_t n, int last) {
   PFA_NEED_INIT();

@@ -96,9 +96,67 @@ class NameTable:
         return int((self.names_off[i + 1] - self.names_off[i]).sum()) + (klen + 2) * len(fidx)
 
 
+class NativePaths:
+    """The path list of an ingest that listed its directory itself (Ingest.from_dir): a sequence of str,
+    decoded on demand — a regular run never asks for one."""
+
+    def __init__(self, ing, n):
+        self._ing, self._n = ing, n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return os.fsdecode(_lib.load().pfa_ingest_path(self._ing.handle, i))
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+
 class Ingest:
     """`paths`: every file the job may read; `feed()` says which of them, in which order, this
     process reads (all of them by default)."""
+
+    @classmethod
+    def from_dir(cls, directory, keys=(), cds=False, threads=0, stride_align=128, slot_bytes=0, n_slots=0):
+        """The reference's `--dir` listing (`[dir + "/" + i for i in os.listdir(dir)]`, sorted; PolyFastA.py:93-94, :104)
+        done by the library: 100 000 names are listed, sorted and kept natively.  Returns None when the library leaves the
+        directory to the caller (a name that is not UTF-8, or a directory it cannot open: os.listdir then raises
+        the reference's own error)."""
+        _lib.init()
+        lib = _lib.load()
+        self = cls.__new__(cls)
+        self.keys = [k.encode("utf-8", "surrogateescape") if isinstance(k, str) else bytes(k) for k in keys]
+        karr = (ctypes.c_char_p * max(len(self.keys), 1))(*self.keys)
+        o = _lib.IngestOptsC(n_threads=int(threads), stride_align=int(stride_align), unit_flags=_lib.PFA_FLAG_CDS if cds else 0,
+                             n_keys=len(self.keys), keys=karr, slot_bytes=int(slot_bytes), n_slots=int(n_slots), reserved=0)
+        h, n = ctypes.c_void_p(), ctypes.c_uint32()
+        rc = lib.pfa_ingest_open_dir(os.fsencode(directory), ctypes.byref(o), ctypes.byref(h), ctypes.byref(n))
+        if rc in (_lib.PFA_ERR_UNSUPPORTED, _lib.PFA_ERR_IO):
+            self.handle = None
+            return None
+        _lib.check(rc)
+        self.handle = h
+        self.cds = bool(cds)
+        self.paths = NativePaths(self, int(n.value))
+        self._bind_names(int(n.value))
+        return self
+
+    def _bind_names(self, n):
+        lib = _lib.load()
+        blob, off = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.pfa_ingest_names(self.handle, ctypes.byref(blob), ctypes.byref(off)))
+        # views of the ingest's own name table: valid until close()
+        noff = np.ctypeslib.as_array(ctypes.cast(off, ctypes.POINTER(ctypes.c_uint64)), shape=(n + 1,))
+        nb = int(noff[-1])
+        nblob = np.ctypeslib.as_array(ctypes.cast(blob, ctypes.POINTER(ctypes.c_uint8)), shape=(nb,)) if nb else np.zeros(1, dtype=np.uint8)
+        self.table = NameTable(nblob, noff, self.keys)
 
     def __init__(self, paths, keys=(), cds=False, threads=0, stride_align=128, slot_bytes=0, n_slots=0):
         _lib.init()
@@ -130,13 +188,7 @@ class Ingest:
         _lib.check(lib.pfa_ingest_open(arr, n, ctypes.byref(o), ctypes.byref(h)))
         self.handle = h
         self.cds = bool(cds)
-        blob, off = ctypes.c_void_p(), ctypes.c_void_p()
-        _lib.check(lib.pfa_ingest_names(h, ctypes.byref(blob), ctypes.byref(off)))
-        # views of the ingest's own name table: valid until close()
-        noff = np.ctypeslib.as_array(ctypes.cast(off, ctypes.POINTER(ctypes.c_uint64)), shape=(n + 1,))
-        nb = int(noff[-1])
-        nblob = np.ctypeslib.as_array(ctypes.cast(blob, ctypes.POINTER(ctypes.c_uint8)), shape=(nb,)) if nb else np.zeros(1, dtype=np.uint8)
-        self.table = NameTable(nblob, noff, self.keys)
+        self._bind_names(n)
 
     def feed(self, idx=None, last=True):
         lib = _lib.load()
@@ -162,7 +214,7 @@ class Ingest:
                 "bytes_copied": int(buf[4]), "loader_threads": int(buf[5]), "turn_wait_thread_s": buf[6], "batches": int(buf[7])}
 
     def close(self):
-        if self.handle is not None and self.handle.value:
+        if getattr(self, "handle", None) is not None and self.handle.value:
             _lib.load().pfa_ingest_close(self.handle)
         self.handle = None
 

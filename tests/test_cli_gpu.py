@@ -217,3 +217,27 @@ def test_ingest_soak_mixed_directory(gpu, tmp_path, monkeypatch):
         rc, out = run_cli(["-d", str(tmp_path), "-s"])
         got = {ln.split(",")[0]: (int(ln.split(",")[4]), int(ln.split(",")[1]), int(ln.split(",")[3])) for ln in out.splitlines()}
         assert got == want, (rep, {k: (got.get(k), want[k]) for k in want if got.get(k) != want[k]})
+
+
+def test_directory_listed_by_the_library_in_the_reference_order(gpu, tmp_path):
+    """`--dir`: the library lists and sorts the directory itself; the rows come out in the order of
+    `sorted(dir + "/" + name for name in os.listdir(dir))` (PolyFastA.py:93-94, :104) — digits, case, a dot file,
+    multi-byte UTF-8 names — and a name that is not UTF-8 sends the listing back to Python (same rows)."""
+    names = ["file10.fa", "file2.fa", "File3.fa", "a b.fa", ".hidden.fa", "zeta.fa", "\u00e9clair.fa", "\u4e2d\u6587.fa", "~tilde.fa", "Z.fa", "_x.fa"]
+    p = synth.make_params(8, 0.05)
+    for k, nm in enumerate(names):
+        (tmp_path / nm).write_text(synth.to_fasta_text(synth.headers_for(8), synth.synth_alignment(31, k, 300 + k, p)))
+    want = [x.split("/")[-1] for x in sorted(str(tmp_path) + "/" + i for i in os.listdir(tmp_path))]
+    rc, out = run_cli(["-d", str(tmp_path), "-s"])
+    got = [ln.split(",")[0] for ln in out.splitlines()]
+    assert rc == 0 and got == want and len(got) == len(names)
+    lens = {ln.split(",")[0]: int(ln.split(",")[1]) for ln in out.splitlines()}
+    assert all(lens[nm] == 300 + k for k, nm in enumerate(names))
+    # a name that is not UTF-8: the library declines (Python would sort the escaped bytes by code point, and the
+    # reference itself cannot print such a name): the caller lists the directory the reference's way
+    from polyfasta_amd import ingest
+    with open(os.fsencode(str(tmp_path)) + b"/caf\xe9.fa", "wb") as fh:
+        fh.write(b">a\nACGT\n>b\nACGA\n")
+    assert ingest.Ingest.from_dir(str(tmp_path)) is None
+    ing = ingest.Ingest.from_dir(str(tmp_path.parent / "no_such_directory"))
+    assert ing is None
