@@ -645,6 +645,7 @@ def main():
         def bail():
             if rank == 0:
                 import shutil
+                time.sleep(0.5)                                              # the other ranks' watchdogs fire with this one: let them stop writing
                 shutil.rmtree(e2e_ranks_paths()[0], ignore_errors=True)      # gigabytes of tmpfs: not left behind
                 line["end_to_end"] = {"error": f"the N > 1 end-to-end leg did not finish within {args.e2e_ranks_timeout} s"}
                 print(json.dumps(line), flush=True)
