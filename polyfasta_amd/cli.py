@@ -540,6 +540,24 @@ startup_marks = []  # (phase that ENDS here, wall clock): __main__ and main() ap
 last_stats = {}     # what the last run_files() measured (bench.py `end_to_end`: the stage breakdown)
 
 
+def text_runs(blk, table, args):
+    """The rows of a sorted block as text, one piece per run of consecutive files: [(first file index, text)], or None
+    when some row needs the Python path.  (A rank of a multi-GPU job owns whole claims of the shared queue: its rows are
+    a few dozen such runs.)"""
+    fidx = blk.meta["fidx"].astype(np.int64)
+    if len(fidx) == 0:
+        return []
+    cuts = np.flatnonzero(np.diff(fidx) > 1) + 1
+    out = []
+    for a, b in zip(np.concatenate(([0], cuts)).tolist(), np.concatenate((cuts, [len(fidx)])).tolist()):
+        part = RowBlock(blk.meta[a:b], blk.rec[a:b], None if blk.syn is None else blk.syn[a:b])
+        text = format_block_native(part, table, args.cds, args.jc)
+        if text is None:
+            return None
+        out.append((int(fidx[a]), text))
+    return out
+
+
 def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
     """`paths`: the sorted file list — or None with `directory`: the library lists and sorts it itself
     (PolyFastA.py:93-94, :104; falls back to os.listdir where it declines).
@@ -609,11 +627,25 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
             if trace is not None:
                 trace.append(("batch", t0 - t00, b.n_files, t1 - t0, t2 - t1, t3 - t2))
         if world > 1:
-            mine = RowBlock.concat(kept, args.cds)
-            parts = comm.gather_bytes(mine.to_bytes(), dst=0)
-            if rank == 0:
-                allb = RowBlock.concat([RowBlock.from_bytes(p) for p in parts], args.cds).sorted()
-                emit_block(allb, sink, args, ing.table, paths, keys)
+            # Every rank formats its own rows (natively, in parallel) as runs of consecutive files — a claim of the queue is
+            # such a run — and rank 0 only puts the runs of all ranks in file order: its share of the work does not grow with
+            # the number of ranks.  When some rank holds anything but plain rows (comment lines, --sfs, the progress chatter of
+            # --out without --silent, a row the native formatter hands back) the blocks travel instead and rank 0 formats.
+            import pickle
+            mine = RowBlock.concat(kept, args.cds).sorted()
+            runs = text_runs(mine, ing.table, args) if (not mine.specials and not args.sfs and sink.bulk_ok()) else None
+            flags = comm.all_gather_fixed(np.array([runs is not None], dtype=np.uint8))
+            if bool(flags.all()):
+                parts = comm.gather_bytes(pickle.dumps(runs, protocol=pickle.HIGHEST_PROTOCOL), dst=0)
+                if rank == 0:
+                    allruns = sorted((r for p in parts for r in pickle.loads(p)), key=lambda r: r[0])
+                    if allruns:
+                        sink.rows("".join(r[1] for r in allruns))
+            else:
+                parts = comm.gather_bytes(mine.to_bytes(), dst=0)
+                if rank == 0:
+                    allb = RowBlock.concat([RowBlock.from_bytes(p) for p in parts], args.cds).sorted()
+                    emit_block(allb, sink, args, ing.table, paths, keys)
         if trace is not None:
             trace.append(("loop_end", time.perf_counter() - t00))
         if comm is not None:

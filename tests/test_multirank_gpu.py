@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _make_dir(tmp_path, n_files=37):
+def _make_dir(tmp_path, n_files=37, odd=True):
     d = tmp_path / "aln"
     d.mkdir()
     rng = np.random.default_rng(5)
@@ -27,8 +27,9 @@ def _make_dir(tmp_path, n_files=37):
         p = synth.make_params(n, 0.02)
         m = synth.synth_alignment(4200, i, L, p, coding=True)
         (d / f"g{i:02d}.fa").write_text(synth.to_fasta_text(synth.headers_for(n, 2), m))
-    (d / "zz_not_fasta.fa").write_text("no header here\nACGT\n")
-    (d / "zz_unequal.fa").write_text(">pop1_a\nACGT\n>pop2_b\nACG\n")
+    if odd:
+        (d / "zz_not_fasta.fa").write_text("no header here\nACGT\n")
+        (d / "zz_unequal.fa").write_text(">pop1_a\nACGT\n>pop2_b\nACG\n")
     return d
 
 
@@ -45,6 +46,27 @@ def test_two_rank_cli_equals_single_process(gpu, tmp_path, extra):
     argv = ["-d", str(d), "-s"] + extra
     want = _single(argv)
     assert want.count("\n") > 37
+    out = tmp_path / "rank0.csv"
+    port = dist._free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_cli_rank_worker.py"), str(out)] + argv,
+                                      env=env, cwd=ROOT, stderr=subprocess.PIPE))
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err.decode()[-3000:]
+    assert open(out).read() == want
+
+
+@pytest.mark.parametrize("extra", [[], ["--cds", "--jc", "-p", "pop1,pop2"]])
+def test_two_rank_cli_regular_directory_rows_formatted_by_their_ranks(gpu, tmp_path, extra):
+    """A directory of regular files only: every rank formats its own rows as runs of consecutive files and rank 0
+    puts the runs in file order (cli.text_runs) — byte for byte the single process's CSV."""
+    d = _make_dir(tmp_path, n_files=61, odd=False)
+    argv = ["-d", str(d), "-s"] + extra
+    want = _single(argv)
+    assert want.count("\n") >= 61
     out = tmp_path / "rank0.csv"
     port = dist._free_port()
     procs = []
