@@ -127,6 +127,12 @@ __global__ void __launch_bounds__(256) repack_kernel(const uint8_t* __restrict__
   }
 }
 
+void warm_ingest() {   // pfa_prewarm: load this translation unit's code object
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(repack_kernel));
+  (void)hipGetLastError();
+}
+
 static int launch_repack(const uint8_t* text, const Seg* segs, uint32_t n_segs, uint8_t* packed, uint32_t stride_align, uint32_t* bad, hipStream_t st) {
   hipLaunchKernelGGL(repack_kernel, dim3(n_segs < (1u << 20) ? n_segs : (1u << 20)), dim3(256), 0, st, text, segs, n_segs, packed, stride_align, bad);
   PFA_HIP(hipGetLastError());
@@ -212,6 +218,9 @@ struct pfa_ingest {
   std::vector<std::string> keys;
   uint32_t stride_align = 128, unit_flags = 0, want_threads = 0, n_slots = pfa::kDefaultSlots, n_dev_slots = 2 * pfa::kDefaultSlots;
   bool pack_rows = true;
+  // a handful of files (the one-file runs of BASELINE configs[1..3]): no copy stream (an HSA queue: 20 ms), no copy engine
+  // (9 ms of SDMA set-up), no device text ring — repack_kernel reads the rows out of the pinned slots over PCIe
+  bool direct = false;
   size_t max_slot = pfa::kDefaultSlot;
   int device = 0;
 
@@ -323,12 +332,12 @@ int new_use(pfa_ingest* g, std::unique_lock<std::mutex>& lk, size_t need, uint32
     // handful of files, slots are not sized below 4 MiB; they are allocated one by one as they come into use)
     if (remaining > 8) est = std::max(est, size_t(4) << 20);
     g->slot_bytes = std::min(std::max(est, kMinSlot), g->max_slot);
-    const size_t want = (size_t)g->n_dev_slots * g->slot_bytes + 256u;
-    {
+    const size_t want = g->direct ? 0 : (size_t)g->n_dev_slots * g->slot_bytes + 256u;
+    if (want) {
       std::lock_guard<std::mutex> ck(g_cache.mu);
       if (g_cache.d_text_cap >= want) { g->d_text = g_cache.d_text; g->d_text_cap = g_cache.d_text_cap; g_cache.d_text = nullptr; g_cache.d_text_cap = 0; }
     }
-    if (!g->d_text) {
+    if (want && !g->d_text) {
       if (hipMalloc((void**)&g->d_text, want) != hipSuccess) { (void)hipGetLastError(); fail(g, PFA_ERR_NOMEM, "ingest: cannot allocate the device text ring"); return -1; }
       g->d_text_cap = want;
     }
@@ -339,7 +348,7 @@ int new_use(pfa_ingest* g, std::unique_lock<std::mutex>& lk, size_t need, uint32
     lk.unlock();
     Pinned p = take_pinned(need);
     uint8_t* d = nullptr;
-    const bool ok = p.h && hipMalloc((void**)&d, need + 256u) == hipSuccess;
+    const bool ok = p.h && (g->direct ? hipHostGetDevicePointer((void**)&d, p.h, 0) == hipSuccess : hipMalloc((void**)&d, need + 256u) == hipSuccess);
     lk.lock();
     if (!ok) { (void)hipGetLastError(); give_pinned(p); fail(g, PFA_ERR_NOMEM, "ingest: cannot allocate buffers for a " + std::to_string(need) + "-byte file"); return -1; }
     u.h = p.h; u.cap = p.cap; u.d = d;
@@ -361,7 +370,11 @@ int new_use(pfa_ingest* g, std::unique_lock<std::mutex>& lk, size_t need, uint32
     u.cap = std::min(g->slot_bytes, std::max(need, kRampSlot << std::min<uint64_t>(g->ring_seq - 1, 8)));
     u.host_slot = hs;
     u.dev_slot = ds;
-    u.d = g->d_text + (size_t)ds * g->slot_bytes;
+    if (g->direct) {
+      if (hipHostGetDevicePointer((void**)&u.d, u.h, 0) != hipSuccess) { fail(g, PFA_ERR_HIP, "ingest: hipHostGetDevicePointer failed"); return -1; }
+    } else {
+      u.d = g->d_text + (size_t)ds * g->slot_bytes;
+    }
   }
   u.ev = take_event(g);
   if (!u.ev) { fail(g, PFA_ERR_HIP, "ingest: hipEventCreate failed"); return -1; }
@@ -559,7 +572,22 @@ void uploader_body(pfa_ingest* g) {
   for (;;) {
     if (g->stop) break;
     const bool have = next_up < g->uses.size() && g->uses[next_up].ready;
+    if (have && g->direct) {       // nothing to copy: the card reads the pinned slot itself
+      g->uses[next_up].enqueued = true;
+      next_up += 1;
+      g->uploaded = next_up;
+      g->cv_batch.notify_all();
+      continue;
+    }
     if (have && inflight.size() < g->max_inflight) {
+      if (!g->copy_stream) {
+        lk.unlock();
+        hipError_t e = hipSuccess;
+        for (uint32_t k = 0; k < g->n_streams && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&g->copy_streams[k], hipStreamNonBlocking);
+        lk.lock();
+        if (e != hipSuccess) { fail(g, PFA_ERR_HIP, "ingest: cannot create the copy stream"); break; }
+        g->copy_stream = g->copy_streams[0];
+      }
       Use& s = g->uses[next_up];
       hipEvent_t wait_ev = nullptr;
       if (!s.big) {
@@ -681,15 +709,7 @@ static int ingest_open_impl(std::vector<std::string>&& paths, const pfa_ingest_o
   }
   if (const char* e = getenv("PFA_INGEST_INFLIGHT")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 16) g->max_inflight = (uint32_t)v; }
   if (const char* e = getenv("PFA_INGEST_STREAMS")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 4) g->n_streams = (uint32_t)v; }
-  for (uint32_t k = 0; k < g->n_streams; ++k)
-    if (hipStreamCreateWithFlags(&g->copy_streams[k], hipStreamNonBlocking) != hipSuccess) {
-      for (uint32_t j = 0; j < k; ++j) (void)hipStreamDestroy(g->copy_streams[j]);
-      delete g;
-      pfa::set_error("pfa_ingest_open: cannot create the copy stream");
-      return PFA_ERR_HIP;
-    }
-  g->copy_stream = g->copy_streams[0];
-  *out = g;
+  *out = g;      // (the copy streams are made by the uploader thread when the first copy is due: a small job never needs one)
   return PFA_OK;
 }
 
@@ -783,6 +803,7 @@ int pfa_ingest_feed(pfa_ingest* g, const uint32_t* file_idx, uint32_t n, int las
     if (last) g->feed_closed = true;
     if (!g->threads_started && (!g->feed.empty() || g->feed_closed)) {
       g->threads_started = true;
+      g->direct = g->feed_closed && g->feed.size() <= std::min<size_t>(4, g->n_slots) && !getenv("PFA_INGEST_NO_DIRECT");   // (slots are never recycled in this mode)
       const uint32_t nt = std::max(1u, std::min<uint32_t>(g->want_threads, (uint32_t)std::max<size_t>(g->feed.size(), 1)));
       g->want_threads = nt;
       for (uint32_t t = 0; t < nt; ++t) g->workers.emplace_back(pfa::worker, g);
@@ -844,7 +865,9 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
     }
     lo = g->consumed;
     hi = lo + 1;
-    if (!g->uses[lo].big) {
+    if (g->direct) {
+      hi = g->uploaded;
+    } else if (!g->uses[lo].big) {
       size_t bytes = g->uses[lo].used;
       while (hi < g->uploaded && !g->uses[hi].big && bytes + g->uses[hi].used <= pfa::kMaxBatchBytes) { bytes += g->uses[hi].used; ++hi; }
     }
@@ -897,7 +920,8 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
     pfa::Seg* const h_segs = reinterpret_cast<pfa::Seg*>(pfa::g_cache.stage.h);
     g->bad_words = reinterpret_cast<uint32_t*>(pfa::g_cache.stage.h + bad_off);
     memset(g->bad_words, 0, (size_t)nf * 4u + 4u);
-    const uint8_t* const text_base = uv.front().big ? uv.front().d : g->d_text;
+    // (direct mode: every use is an allocation of its own and the segments carry absolute addresses)
+    const uint8_t* const text_base = g->direct ? nullptr : uv.front().big ? uv.front().d : g->d_text;
     uint64_t si = 0;
     for (uint32_t b = 0; b < nf; ++b) {
       const pfa::FileRec& f = g->files[bpos[b]];
@@ -907,7 +931,7 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
       const uint64_t base = packed;
       packed += pfa::up256((size_t)(std::max<uint64_t>(f.n_rows, 1) * stride));
       if (f.n_sites) {
-        const uint64_t use_off = (uint64_t)(uv[f.use - lo].d - text_base);
+        const uint64_t use_off = (uint64_t)(reinterpret_cast<uintptr_t>(uv[f.use - lo].d) - reinterpret_cast<uintptr_t>(text_base));
         for (uint32_t r = 0; r < f.n_rows; ++r)
           h_segs[si++] = pfa::Seg{use_off + (f.row_off[r] & ~pfa::kRowPacked), base + (uint64_t)r * stride, f.n_sites,
                                   b | ((f.row_off[r] & pfa::kRowPacked) ? pfa::kSegPacked : 0u)};
@@ -964,7 +988,8 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
     if (rc != PFA_OK) return rc;
     // everything below is enqueued behind the copies of this batch's slots
     // (copies of one stream complete in order; with several copy streams every slot's event is waited for)
-    for (size_t k = g->n_streams > 1 ? 0 : uv.size() - 1; k < uv.size(); ++k) PFA_HIP(hipStreamWaitEvent(st, uv[k].ev, 0));
+    if (!g->direct)
+      for (size_t k = g->n_streams > 1 ? 0 : uv.size() - 1; k < uv.size(); ++k) PFA_HIP(hipStreamWaitEvent(st, uv[k].ev, 0));
     g->launched = true;
     if (n_segs) {
       uint32_t* d_bad = nullptr;
@@ -986,7 +1011,7 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
       for (uint32_t u = lo; u < hi; ++u) {
         g->uses[u].consumed = true;
         g->uses[u].repack_ev = bev;
-        if (g->uses[u].big) g->big_dev.push_back(g->uses[u].d);
+        if (g->uses[u].big && !g->direct) g->big_dev.push_back(g->uses[u].d);
         // the rows of these files are on their way: their tables can go
         for (uint32_t p : g->uses[u].pos) {
           pfa::FileRec& f = g->files[p];
@@ -1053,14 +1078,14 @@ void pfa_ingest_close(pfa_ingest* g) {
   if (g->uploader.joinable()) g->uploader.join();
   const bool live = pfa::ctx().ready;
   if (live) {
-    for (uint32_t k = 0; k < g->n_streams; ++k) (void)hipStreamSynchronize(g->copy_streams[k]);
+    for (uint32_t k = 0; k < g->n_streams; ++k) if (g->copy_streams[k]) (void)hipStreamSynchronize(g->copy_streams[k]);
     release_batch(g);
     (void)hipStreamSynchronize(pfa::ctx().stream);
   }
   for (pfa::Use& u : g->uses) {
     if (u.ev) (void)hipEventDestroy(u.ev);
     if (u.big) {   // oversized files that never reached a batch, or whose copy was never waited for
-      if (!u.consumed) (void)hipFree(u.d);
+      if (!u.consumed && !g->direct) (void)hipFree(u.d);
       if (u.h) { g->big_pinned_done.push_back(pfa::Pinned{u.h, u.cap}); u.h = nullptr; }
     }
   }

@@ -22,6 +22,9 @@ struct LaunchCfg {
 
 int launch_classic(const LaunchCfg& c, const ScanArgs& a, hipStream_t st);
 int launch_tall(const LaunchCfg& c, const ScanArgs& a, hipStream_t st);
+// load the translation unit's code object now (pfa_prewarm): hipFuncGetAttributes on one of its kernels
+void warm_classic();
+void warm_ingest();
 int launch_classify_masks(const unsigned long long* d_masks, uint32_t n, uint32_t* d_labels, hipStream_t st);
 
 }  // namespace pfa

@@ -222,23 +222,7 @@ int pfa_device_count(void) {
   return n;
 }
 
-// hipInit on a thread of its own, started by the command line before it imports its modules
-static std::thread g_prewarm;
-
-void pfa_prewarm(int device) {
-  if (pfa::ctx().ready || g_prewarm.joinable()) return;
-  try {
-    g_prewarm = std::thread([device]() {
-      int n = 0;
-      if (hipGetDeviceCount(&n) == hipSuccess && device >= 0 && device < n && hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
-      (void)hipGetLastError();
-    });
-  } catch (...) {
-  }
-}
-
-int pfa_init(int device) {
-  if (g_prewarm.joinable()) g_prewarm.join();
+static int init_impl(int device) {
   pfa::Context& c = pfa::ctx();
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -249,7 +233,7 @@ int pfa_init(int device) {
     pfa::set_error("device %d out of range (0..%d)", device, n - 1);
     return PFA_ERR_ARG;
   }
-  if (c.ready && c.device == device) return PFA_OK;
+  if (c.ready && c.device == device) { PFA_HIP(hipSetDevice(device)); return PFA_OK; }   // (the device is a per-thread setting)
   if (c.ready) pfa_shutdown();
   PFA_HIP(hipSetDevice(device));
   // host waits spin instead of sleeping on an interrupt: a blocked wait was seen to return
@@ -269,6 +253,40 @@ int pfa_init(int device) {
   c.device = device;
   c.ready = true;
   return PFA_OK;
+}
+
+// The whole start-up of a one-file run on a thread of the library's own, started by the command line before it imports
+// its modules (tools/ubench/init_probe.hip: hipInit 50-230 ms, a stream = an HSA queue 20 ms, the first H2D copy 9 ms of SDMA
+// set-up, a translation unit's code object on its first launch): context, stream, the code objects of the scan / plan / ingest
+// kernels and the copy engine are up by the time Python has imported numpy.  pfa_init() waits for it.
+static std::thread g_prewarm;
+
+void pfa_prewarm(int device) {
+  if (pfa::ctx().ready || g_prewarm.joinable()) return;
+  try {
+    g_prewarm = std::thread([device]() {
+      if (init_impl(device) != PFA_OK) return;       // (pfa_init() repeats it on the caller's thread and reports the error there)
+      hipFuncAttributes fa;
+      (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(pfa::slab_to_host_kernel));
+      pfa::warm_classic();
+      pfa::warm_ingest();
+      void *h = nullptr, *d = nullptr;
+      if (hipHostMalloc(&h, 4096, hipHostMallocDefault) == hipSuccess && hipMalloc(&d, 4096) == hipSuccess) {
+        memset(h, 0, 4096);
+        (void)hipMemcpyAsync(d, h, 4096, hipMemcpyHostToDevice, pfa::ctx().stream);
+        (void)hipStreamSynchronize(pfa::ctx().stream);
+      }
+      if (d) (void)hipFree(d);
+      if (h) (void)hipHostFree(h);
+      (void)hipGetLastError();
+    });
+  } catch (...) {
+  }
+}
+
+int pfa_init(int device) {
+  if (g_prewarm.joinable()) g_prewarm.join();
+  return init_impl(device);
 }
 
 void pfa_shutdown(void) {

@@ -390,6 +390,12 @@ int launch_classic(const LaunchCfg& c, const ScanArgs& a, hipStream_t st) {
   return launch_features<2, false, 64>(c, a, st);
 }
 
+void warm_classic() {
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(scan_kernel<2, false, false, false, 128>));
+  (void)hipGetLastError();
+}
+
 int launch_classify_masks(const unsigned long long* d_masks, uint32_t n, uint32_t* d_labels, hipStream_t st) {
   hipLaunchKernelGGL(classify_masks_kernel, dim3(n < 4096u ? n : 4096u), dim3(64), 0, st, d_masks, n, d_labels);
   PFA_HIP(hipGetLastError());
