@@ -6,7 +6,7 @@
 #include <cstring>
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 __global__ void k(int* p) { if (p) *p = 1; }
-int main() {
+int main(int argc, char**) {
   double t = now(), t0 = t;
   auto lap = [&](const char* what) { const double n = now(); printf("%-44s %8.2f ms\n", what, (n - t) * 1e3); t = n; };
   int n = 0;
@@ -17,7 +17,12 @@ int main() {
   (void)hipSetDeviceFlags(hipDeviceScheduleSpin); lap("hipSetDeviceFlags");
   hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, 0); lap("hipGetDeviceProperties");
   int cu = 0; (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, 0); lap("hipDeviceGetAttribute");
-  hipStream_t st; (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking); lap("hipStreamCreateWithFlags");
+  hipStream_t st = nullptr;
+  if (argc > 1) {      // any argument: stay on the NULL stream (is its queue cheaper than a created stream's?)
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, nullptr, (int*)nullptr); (void)hipStreamSynchronize(nullptr); lap("first kernel launch on the NULL stream + sync");
+  } else {
+    (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking); lap("hipStreamCreateWithFlags");
+  }
   void* d = nullptr; (void)hipMalloc(&d, 1 << 20); lap("hipMalloc 1 MiB");
   void* h = nullptr; (void)hipHostMalloc(&h, 1 << 20, 0); lap("hipHostMalloc 1 MiB");
   hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, st, (int*)d); (void)hipStreamSynchronize(st); lap("first kernel launch + sync (code object)");
