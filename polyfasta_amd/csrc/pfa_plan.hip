@@ -162,12 +162,15 @@ struct Bucket {
   std::vector<uint32_t> units;
 };
 
-// classic kernel: LDS-resident tiles keep the CU full when at least 5 wavefronts fit whose tiles
+// classic kernel: LDS-resident tiles keep the CU full when at least 6 wavefronts fit whose tiles
 // add up to 125 KB of loads in flight (measured round 1: N = 100 x 256 sites, 6 waves, 6.45 TB/s
-// against 6.03 row-chunked; N = 128, 4 waves, 5.84 against 5.88; N = 160, 3 waves, 5.04 against 6.06)
+// against 6.03 row-chunked; N = 128, 4 waves, 5.84 against 5.88; N = 160, 3 waves, 5.04 against 6.06;
+// round 3, 128-site tiles, classic / row-chunked (tools/rows_sweep.sh): 6 waves — N = 192 0.771 / 0.765, 200 0.766 / 0.762,
+// coding 0.736 / 0.664 and 0.720 / 0.709; 5 waves — N = 208 0.691 / 0.726, 224 0.719 / 0.726, 250 0.612 / 0.715, coding 208
+// 0.618 / 0.664, 224 0.652 / 0.659)
 static bool classic_fills_cu(uint32_t lds_bytes, uint32_t n, uint32_t tw) {
   const uint32_t waves = kLdsPerCu / std::max(lds_bytes, 1u);
-  return waves >= 5u && (uint64_t)waves * n * tw >= 125000ull;
+  return waves >= 6u && (uint64_t)waves * n * tw >= 125000ull;
 }
 
 }  // namespace pfa
