@@ -67,11 +67,15 @@ def parse(argv=None):
 class Workload:
     """A device-resident batch of synthetic alignments and its scan plan."""
 
-    def __init__(self, rows, sites, batch, theta=0.01, coding=False, pops=0, stride_align=128, first_aln=0, timing=True):
+    def __init__(self, rows, sites, batch, theta=0.01, coding=False, pops=0, stride_align=128, first_aln=0, timing=True, split=0):
+        """`pops`: row-index lists over one matrix (the ABI's pfa_desc.row_idx form).  `split`: the form the command line produces for
+        --pops (csrc/pfa_ingest.hip): every population a matrix of its own — `split` matrices of `rows` rows per alignment."""
+        if split:
+            batch, pops = batch * split, 0
         from polyfasta_amd import _lib, scan, synth
         lib = _lib.load()
         self.N, self.L, self.B, self.K = rows, sites, batch, max(pops, 1)
-        self.coding, self.pops = coding, pops
+        self.coding, self.pops, self.split = coding, pops, split
         NM = rows * self.K
         self.params = synth.make_params(NM, theta)
         self.stride = scan.row_stride_for(sites, stride_align)
@@ -98,6 +102,9 @@ class Workload:
 
     def label(self):
         s = f"{self.B} distinct alignments, N={self.N} x L={self.L}, {'coding (--cds)' if self.coding else 'non-coding'}"
+        if self.split:
+            s = (f"{self.B // self.split} alignments of {self.N * self.split} rows x L={self.L} as the command line lays --pops out: {self.split} populations of {self.N} "
+                 f"rows, each a matrix of its own ({self.B} units), {'coding (--cds)' if self.coding else 'non-coding'}")
         if self.pops:
             s += f", {self.K} populations of {self.N} rows per {self.N * self.K}-row matrix (--pops)"
         return s
@@ -130,7 +137,10 @@ def extra_workloads(args):
     """The other BASELINE shapes as short device-resident passes (kernel time from HIP events)."""
     out = {}
     for key, kw in (("C4_coding_50x9000", dict(rows=50, sites=9000, batch=32768, coding=True)),
-                    ("C3_pops_2x100x100000", dict(rows=100, sites=100000, batch=128, pops=2)),
+                    # BASELINE configs[2] (200 x 100 kb, --pops pop1,pop2): as the CLI's ingest lays it out (one matrix per population), and
+                    # through the ABI's row-index lists over one 200-row matrix
+                    ("C3_pops_2x100x100000", dict(rows=100, sites=100000, batch=128, split=2)),
+                    ("C3_pops_row_index_lists", dict(rows=100, sites=100000, batch=128, pops=2)),
                     ("N200_plain_200x100000", dict(rows=200, sites=100000, batch=128)),
                     ("N200_coding_200x9000", dict(rows=200, sites=9000, batch=8192, coding=True)),
                     # units with many rows: the row-chunked kernel (and its wide form above 2 048 coding rows)

@@ -241,13 +241,13 @@ int main(int argc, char** argv) {
         for (const auto& rows : sel) {
           CHECK(u < b.n_units && b.unit_file[u] == f && b.unit_rows[u] == rows.size(), "round %d file %u: unit table", round, gi);
           const pfa_desc& d = b.plan->descs[u];
-          CHECK(d.n_rows == rows.size() && d.n_sites == e.rows[0].size() && d.mat_rows == e.rows.size() && d.row_stride % 16 == 0 &&
-                    d.base_off % 256 == 0 && d.base_off + (uint64_t)d.mat_rows * d.row_stride <= b.plan->n_bytes,
+          // a unit is a matrix of its own: all records of the file, or — population split — the records its key names, in record order
+          CHECK(d.n_rows == rows.size() && d.n_sites == e.rows[0].size() && d.mat_rows == rows.size() && d.row_idx_off == PFA_NO_ROW_IDX &&
+                    d.row_stride % 16 == 0 && d.base_off % 256 == 0 && d.base_off + (uint64_t)d.mat_rows * d.row_stride <= b.plan->n_bytes,
                 "round %d file %u: descriptor", round, gi);
           for (uint32_t k = 0; k < rows.size(); ++k) {
-            const uint32_t r = d.row_idx_off == PFA_NO_ROW_IDX ? k : b.plan->ridx[d.row_idx_off + k];
-            CHECK(r == rows[k], "round %d file %u: row index", round, gi);
-            const uint8_t* got = b.plan->bases + d.base_off + (uint64_t)r * d.row_stride;
+            const uint32_t r = rows[k];
+            const uint8_t* got = b.plan->bases + d.base_off + (uint64_t)k * d.row_stride;
             CHECK(memcmp(got, e.rows[r].data(), d.n_sites) == 0, "round %d file %u row %u: bytes differ (threads %u, slot %llu)", round, gi, r,
                   o.n_threads, (unsigned long long)o.slot_bytes);
             for (uint32_t c = d.n_sites; c < d.row_stride && d.n_sites; ++c) CHECK(got[c] == 0, "round %d file %u row %u: padding", round, gi, r);
