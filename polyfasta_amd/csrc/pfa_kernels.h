@@ -120,9 +120,28 @@ __device__ inline uint32_t wave_or_uniform(uint32_t v) {
   v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// both halves step by step, so that one chain's instruction fills the other's DPP wait states
 __device__ inline unsigned long long wave_or_uniform(unsigned long long v) {
-  return (unsigned long long)wave_or_uniform((uint32_t)v) | (unsigned long long)wave_or_uniform((uint32_t)(v >> 32)) << 32;
+  uint32_t a = (uint32_t)v, b = (uint32_t)(v >> 32);
+#define PFA_OR_STEP(ctrl, rows)                                                          \
+  a |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, ctrl, rows, 0xF, false); \
+  b |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, ctrl, rows, 0xF, false);
+  PFA_OR_STEP(0xB1, 0xF)
+  PFA_OR_STEP(0x4E, 0xF)
+  PFA_OR_STEP(0x141, 0xF)
+  PFA_OR_STEP(0x140, 0xF)
+  PFA_OR_STEP(0x142, 0xA)
+  PFA_OR_STEP(0x143, 0xC)
+#undef PFA_OR_STEP
+  return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)a, 63) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)b, 63) << 32;
 }
+// a value the program knows to be the same in every lane, made a scalar for the compiler
+__device__ inline unsigned long long wave_uniform(unsigned long long v) {
+  return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+         (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
+}
+// bit 7 of every byte of `v` that is not zero
+__device__ inline uint32_t byte_nonzero_bits(uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; }
 __device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ inline uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 

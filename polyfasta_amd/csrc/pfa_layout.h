@@ -82,6 +82,10 @@ struct ScanArgs {
   uint32_t rep_stride;
 };
 
+// Rows per chunk of the row-chunked kernel: chunks of exactly this many rows run straight-line code (staging, tier 1, tier 2);
+// the plan cuts every unit into such chunks and a shorter last one.  (Rows per chunk swept 28..64 at N = 1 000 / 5 000: flat.)
+static constexpr uint32_t kTallRowsFast = 48u;
+
 struct TallLayout {
   uint32_t tile, list, cnt, hist, hsite, synhist, cslots, total;
 };

@@ -92,7 +92,6 @@ __global__ void __launch_bounds__(256) sum_replicas_kernel(unsigned long long* s
 }
 
 static constexpr uint32_t kLdsPerCu = 160u * 1024u;
-static constexpr uint32_t kTallRows = 48u;      // rows per chunk of the row-chunked kernel (upper bound)
 static constexpr uint32_t kTallSlots = 64u;     // its count-table slots per tile (measured: 64 6.03, 96 5.68 TB/s at N = 100)
 static constexpr int kEventRing = 64;
 
@@ -479,10 +478,15 @@ static void finish_bucket(Bucket& b, const BucketKey& k, bool bitmaps, const pfa
     b.bytes += (uint64_t)d.n_rows * d.n_sites;
   }
   if (b.tall) {
-    // equal chunks of at most kTallRows rows (a multiple of 4: one LDS-DMA instruction moves 4 rows)
-    const uint32_t rcap = std::min(64u, std::max(8u, env_u32("PFA_TALL_ROWS", kTallRows)));
-    const uint32_t nc = (b.n_max + rcap - 1u) / rcap;
-    b.rows_per_chunk = std::min(64u, std::max(8u, ((b.n_max + nc - 1u) / nc + 3u) & ~3u));
+    // chunks of kTallRowsFast rows and a shorter last one (a multiple of 4: one LDS-DMA instruction moves 4 rows);
+    // PFA_TALL_ROWS (timing experiments, tests of the general path): equal chunks of at most that many rows
+    if (getenv("PFA_TALL_ROWS")) {
+      const uint32_t rcap = std::min(64u, std::max(8u, env_u32("PFA_TALL_ROWS", kTallRowsFast)));
+      const uint32_t nc = (b.n_max + rcap - 1u) / rcap;
+      b.rows_per_chunk = std::min(64u, std::max(8u, ((b.n_max + nc - 1u) / nc + 3u) & ~3u));
+    } else {
+      b.rows_per_chunk = std::min(kTallRowsFast, std::max(8u, (b.n_max + 3u) & ~3u));
+    }
     b.max_slots = std::min(256u, std::max(16u, env_u32("PFA_TALL_SLOTS", kTallSlots)));
     b.hist_bins = std::min(b.n_max / 2u, 256u);
     b.cfg.lds_bytes = tall_layout(b.rows_per_chunk, b.max_slots, b.hist_bins, b.cfg.cds, b.cfg.wide).total;

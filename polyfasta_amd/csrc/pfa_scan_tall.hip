@@ -6,6 +6,9 @@
 // getvarCDSsites :284-315 (no row limit there).
 #include "pfa_kernels.h"
 #include "pfa_launch.h"
+#ifndef PFA_TALL_PROBE
+#define PFA_TALL_PROBE 0
+#endif
 
 namespace pfa {
 
@@ -90,6 +93,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
   constexpr uint32_t MSH = WIDE ? 56u : 24u;   // hsite entry: H | allele mask << MSH
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   constexpr uint32_t TW = 256u;
+  constexpr uint32_t RF = kTallRowsFast;   // chunks of exactly this many rows run straight-line code (the plan's default chunk)
   const uint32_t lane = threadIdx.x;
   const uint32_t unit = A.unit_ids ? A.unit_ids[blockIdx.x] : blockIdx.x;
   const pfa_desc D = A.descs[unit];
@@ -187,18 +191,48 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
 
   // ---------------- stage rows [r0, r0 + Rc) x 256 sites of a tile (asynchronous for LDS-DMA)
   const uint32_t c16 = lane % 16u, rr = lane / 16u;
+  typedef __attribute__((address_space(3))) uint8_t* lds8_t;
+  const lds8_t tile3 = (lds8_t)tile8;   // LDS address arithmetic in its own address space (no null checks per instruction)
   auto stage_chunk = [&](uint32_t tile, uint32_t r0, uint32_t idx_rows) {
     const uint32_t Rc = umin(R, N - r0);
     const uint32_t col = umin(tile * TW + 16u * c16, D.row_stride - 16u);
+    if (!mapped) {
+      const uint64_t step = (uint64_t)D.row_stride * 4u;
+      if (Rc == RF) {
+        // a whole chunk, written out: twelve loads, the address a 64-bit add and the LDS offset (M0) a scalar add apart;
+        // the M0 write and the next load are separated by the address update (one wait state is required).
+        // (Left to the compiler, the twelve addresses sit in 24 VGPRs and the twelve LDS offsets in spilled SGPRs.)
+        static_assert(RF == 48u, "twelve LDS-DMA instructions below");
+        const uint8_t* src = mat + (uint64_t)(r0 + rr) * D.row_stride + col;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)tile3;
+#define PFA_LD(pol) "global_load_lds_dwordx4 %0, off" pol "\n\ts_add_u32 m0, m0, 0x400\n\tv_lshl_add_u64 %0, %0, 0, %2\n\t"
+#define PFA_LD12(pol) "s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t" PFA_LD(pol) PFA_LD(pol) PFA_LD(pol) PFA_LD(pol) PFA_LD(pol) PFA_LD(pol) \
+                      PFA_LD(pol) PFA_LD(pol) PFA_LD(pol) PFA_LD(pol) PFA_LD(pol) "global_load_lds_dwordx4 %0, off" pol "\n\ts_mov_b32 m0, %1"
+        uint32_t m0_saved;   // M0 is the compiler's: handed back as found
+        if constexpr (STAGE == 2) asm volatile(PFA_LD12(" nt") : "+v"(src), "=&s"(m0_saved) : "s"(step), "s"(lds0) : "memory", "scc");
+        else asm volatile(PFA_LD12("") : "+v"(src), "=&s"(m0_saved) : "s"(step), "s"(lds0) : "memory", "scc");
+#undef PFA_LD12
+#undef PFA_LD
+        return;
+      }
+      // one address per lane and chunk, then a 64-bit step per instruction; whole groups of 4 rows need no predicate
+      const uint8_t* src = mat + (uint64_t)(r0 + rr) * D.row_stride + col;
+      const uint32_t n_full = Rc >> 2;
+      uint32_t g = 0;
+#pragma unroll 4
+      for (; g < n_full; ++g) {
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile3 + g * 1024u), 16, 0, STAGE);
+        src += step;
+      }
+      if (rr < (Rc & 3u)) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile3 + g * 1024u), 16, 0, STAGE);
+      return;
+    }
     const uint32_t n_inst = (Rc + 3u) / 4u;
     for (uint32_t g = 0; g < n_inst; ++g) {
       const uint32_t r = 4u * g + rr;
-      // mapped: the lanes hold byte offsets of the chunk's rows in 16-byte units
-      const uint32_t held = mapped ? (uint32_t)__shfl((int)idx_rows, (int)(r & 63u)) : 0u;
-      if (r < Rc) {
-        const uint8_t* src = mat + (mapped ? (uint64_t)held << 4 : (uint64_t)(r0 + r) * D.row_stride) + col;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile8 + g * 1024u), 16, 0, STAGE);
-      }
+      // the lanes hold byte offsets of the chunk's rows in 16-byte units
+      const uint32_t held = (uint32_t)__shfl((int)idx_rows, (int)(r & 63u));
+      if (r < Rc) __builtin_amdgcn_global_load_lds((gptr_t)(mat + ((uint64_t)held << 4) + col), (lptr_t)(tile3 + g * 1024u), 16, 0, STAGE);
     }
   };
   // A chunk is requested as soon as the previous one has been read for the last time: the next
@@ -235,6 +269,10 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wave_lds_sync();
+#if PFA_TALL_PROBE == 1
+      if (r0 + R < N) stage_chunk(tile, r0 + R, idx_cur); else if (tile + 1u < t1) stage_chunk(tile + 1u, 0u, idx_cur);
+      continue;
+#endif
       if (cds && r0 == 0u && tile > t0) {
         // H of the previous tile's last two sites, for the codons that straddle into this tile
         if (lane < 2u) hsite[(int)lane - 2] = hsite[TW - 2u + lane];
@@ -245,17 +283,49 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       uint32_t ca = 0xFFFFFFFFu, co = 0u;
       const uint32_t x0w = reinterpret_cast<const uint32_t*>(tile8)[lane];   // first row of the chunk
       {
-        const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile8);
-#pragma unroll PFA_UNROLL_T1
-        for (uint32_t r = 0; r < Rc; ++r) {
-          const uint32_t x = t32[r * 64u + lane];
+        // two rows per step, so that AND and OR take their three-input forms (one instruction per row and word);
+        // 16 rows per trip of the main loop: eight paired LDS reads in flight
+        const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile8) + lane;
+        const uint32_t n16 = Rc >> 4;
+#pragma clang loop unroll(disable) vectorize(disable)
+        for (uint32_t i = 0; i < n16; ++i) {
+          // all eight paired reads in flight, then one wait (written out: under register pressure the compiler waits for
+          // every read before it issues the next, eight LDS round trips per 16 rows instead of one)
+          unsigned long long p0, p1, p2, p3, p4, p5, p6, p7;
+          const uint32_t at = (uint32_t)(uintptr_t)(tile8 + i * 4096u) + lane * 4u;
+          asm volatile(
+              "ds_read2st64_b32 %0, %8 offset1:1\n\t"
+              "ds_read2st64_b32 %1, %8 offset0:2 offset1:3\n\t"
+              "ds_read2st64_b32 %2, %8 offset0:4 offset1:5\n\t"
+              "ds_read2st64_b32 %3, %8 offset0:6 offset1:7\n\t"
+              "ds_read2st64_b32 %4, %8 offset0:8 offset1:9\n\t"
+              "ds_read2st64_b32 %5, %8 offset0:10 offset1:11\n\t"
+              "ds_read2st64_b32 %6, %8 offset0:12 offset1:13\n\t"
+              "ds_read2st64_b32 %7, %8 offset0:14 offset1:15\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5), "=&v"(p6), "=&v"(p7)
+              : "v"(at)
+              : "memory");
+          const unsigned long long ps[8] = {p0, p1, p2, p3, p4, p5, p6, p7};
+#pragma unroll
+          for (uint32_t k = 0; k < 8u; ++k) {
+            const uint32_t x0 = (uint32_t)ps[k], x1 = (uint32_t)(ps[k] >> 32);
+            ca = ca & x0 & x1;
+            co = co | x0 | x1;
+          }
+        }
+#pragma clang loop unroll(disable) vectorize(disable)
+        for (uint32_t r = n16 << 4; r < Rc; ++r) {
+          const uint32_t x = t32[r * 64u];
           ca &= x;
           co |= x;
         }
       }
       const uint32_t nva = va & ca, nvo = vo | co, nvd = nva ^ nvo;
 
-      // ---------------- sites that turn variable in this chunk get a count slot
+      // ---------------- sites that turn variable in this chunk get a count slot (most chunks after the first have none)
+      const bool any_new = __any(byte_nonzero_bits(nvd) != byte_nonzero_bits(vd));
+      if (any_new) {
 #pragma unroll
       for (uint32_t b = 0; b < 4u; ++b) {
         const uint32_t off = 4u * lane + b;
@@ -279,6 +349,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
           P += (uint32_t)__popcll(m);
         }
       }
+      }
       const uint32_t va_pre = va, vd_pre = vd, P_prev = umin(P, MAXS);   // state before this chunk
       va = nva;
       vo = nvo;
@@ -288,7 +359,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       wave_lds_sync();
 
       // ---------------- coding units: columns that turn joint in this chunk get a codon slot
-      if (cds) {
+      if (cds && any_new && PFA_TALL_PROBE != 4) {   // a column can only turn joint in a chunk in which one of its sites turns variable
         uint64_t jb_now[2];
         joint_ballots(nvd, jb_now);
 #pragma unroll
@@ -298,7 +369,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
             const int rel = end - 2;
             if (rel < 0 || ncs >= CS) continue;          // read back at the end of the tile
             // the distinct clean codons of the rows before this chunk
-            const unsigned long long S = r0 == 0u ? 0ull : codons_before_chunk(lo.list, lo.cnt, P_prev, va_pre, vd_pre, (uint32_t)rel, lane);
+            const unsigned long long S = r0 == 0u ? 0ull : wave_uniform(codons_before_chunk(lo.list, lo.cnt, P_prev, va_pre, vd_pre, (uint32_t)rel, lane));
             if (S == ~0ull) continue;                    // a position without usable counts: read back
             if (lane == 0u) { cs_end[ncs] = end; cs_set[ncs] = S; }
             ++ncs;
@@ -308,6 +379,10 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
         wave_lds_sync();
       }
 
+#if PFA_TALL_PROBE == 2
+      if (r0 + R < N) stage_chunk(tile, r0 + R, idx_cur); else if (tile + 1u < t1) stage_chunk(tile + 1u, 0u, idx_cur);
+      continue;
+#endif
       // ---------------- tier 2: the chunk's rows of every slotted site
       const uint32_t slot16 = lane >> 2, ph = lane & 3u;
       const uint32_t rows_after = r0 + Rc;
@@ -321,11 +396,42 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
         bool need6 = act && mode == 1u;
         if (act && mode == 0u) {   // the same in all 4 lanes of the quad
           uint32_t c1 = 0, c2 = 0;
-#pragma unroll PFA_UNROLL_T2
-          for (uint32_t r = ph; r < Rc; r += 4u) {
-            const uint32_t v = colp[r * TW];
-            c1 += (v == x);
-            c2 += (v == y);
+          {
+            // lane ph of the quad: rows ph, ph + 4, ...; the trip count is the same in every lane (scalar loop)
+            const uint8_t* q = colp + ph * TW;
+            if (Rc == RF) {
+              static_assert(RF == 48u, "twelve reads per lane below");
+              uint32_t v[12];
+              const uint32_t at = (uint32_t)(uintptr_t)q;
+              asm volatile(   // the twelve reads in flight, one wait (see tier 1)
+                  "ds_read_u8 %0, %12\n\tds_read_u8 %1, %12 offset:1024\n\tds_read_u8 %2, %12 offset:2048\n\t"
+                  "ds_read_u8 %3, %12 offset:3072\n\tds_read_u8 %4, %12 offset:4096\n\tds_read_u8 %5, %12 offset:5120\n\t"
+                  "ds_read_u8 %6, %12 offset:6144\n\tds_read_u8 %7, %12 offset:7168\n\tds_read_u8 %8, %12 offset:8192\n\t"
+                  "ds_read_u8 %9, %12 offset:9216\n\tds_read_u8 %10, %12 offset:10240\n\tds_read_u8 %11, %12 offset:11264\n\t"
+                  "s_waitcnt lgkmcnt(0)"
+                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]),
+                    "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11])
+                  : "v"(at)
+                  : "memory");
+#pragma unroll
+              for (uint32_t i = 0; i < 12u; ++i) {
+                c1 += (v[i] == x);
+                c2 += (v[i] == y);
+              }
+            } else {
+              const uint32_t n4 = Rc >> 2;
+#pragma unroll 4
+              for (uint32_t i = 0; i < n4; ++i) {
+                const uint32_t v = q[i * (4u * TW)];
+                c1 += (v == x);
+                c2 += (v == y);
+              }
+              if (ph < (Rc & 3u)) {
+                const uint32_t v = q[n4 * (4u * TW)];
+                c1 += (v == x);
+                c2 += (v == y);
+              }
+            }
           }
           c1 = quad_sum(c1);
           c2 = quad_sum(c2);
@@ -347,9 +453,11 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
         if (__any(need6)) {
           if (need6) {
             uint32_t cA = 0, cC = 0, cG = 0, cT = 0, cGap = 0, cNn = 0;
+            const uint32_t n4 = (Rc + 3u) >> 2;
 #pragma unroll 4
-            for (uint32_t r = ph; r < Rc; r += 4u) {
-              const uint32_t v = colp[r * TW];
+            for (uint32_t i = 0; i < n4; ++i) {
+              const uint32_t r = 4u * i + ph;
+              const uint32_t v = r < Rc ? colp[r * TW] : 0u;
               cA += (v == 'A');
               cC += (v == 'C');
               cG += (v == 'G');
@@ -375,11 +483,12 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
         }
       }
       // ---------------- coding units: the chunk's rows of every codon slot (one row per lane)
-      for (uint32_t k = 0; k < ncs; ++k) {
-        const uint32_t first = (uint32_t)(cs_end[k] - 2);
+      for (uint32_t k = 0; k < ncs && PFA_TALL_PROBE != 3; ++k) {
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(cs_end[k] - 2);
         const uint8_t* q = tile8 + lane * TW + first;
-        const unsigned long long M = wave_or_uniform(lane < Rc ? codon_bit(q[0], q[1], q[2]) : 0ull);
-        if (lane == 0u) cs_set[k] |= M;
+        const uint32_t b0 = q[0], b1 = q[1], b2 = q[2];
+        const unsigned long long M = wave_or_uniform(lane < Rc ? codon_bit(b0, b1, b2) : 0ull);
+        if (lane == 0u) cs_set[k] |= M;   // (64 lanes OR-ing into the word with an LDS atomic: 0.70 -> 0.49 at N = 1 000)
       }
       wave_lds_sync();   // the tile buffer has been read for the last time
       idx_cur = idx_nxt;

@@ -143,19 +143,21 @@ def test_random_tall_units(gpu, seed):
         _compare(out, i, c_oracle.scan(m, rows=rows, want_sites=True), False)
 
 
-@pytest.mark.parametrize("rows_per_chunk,slots", [(8, 16), (12, 256), (64, 96)])
+@pytest.mark.parametrize("rows_per_chunk,slots", [(8, 16), (12, 256), (64, 96), (None, 16), (None, 64)])
 def test_tall_kernel_forced_on_small_units(gpu, monkeypatch, rows_per_chunk, slots):
     """the same kernel forced onto units of any size (timing-experiment overrides), tiny chunks
-    and a tiny slot table: many chunks per tile and frequent slot overflow"""
+    and a tiny slot table: many chunks per tile and frequent slot overflow; rows_per_chunk None: the
+    plan's own 48-row chunks (the straight-line code of whole chunks) and a shorter last one"""
     monkeypatch.setenv("PFA_TALL_MIN", "0")
-    monkeypatch.setenv("PFA_TALL_ROWS", str(rows_per_chunk))
+    if rows_per_chunk is not None:
+        monkeypatch.setenv("PFA_TALL_ROWS", str(rows_per_chunk))
     monkeypatch.setenv("PFA_TALL_SLOTS", str(slots))
-    rng = np.random.default_rng(7 + rows_per_chunk)
+    rng = np.random.default_rng(7 + (rows_per_chunk or slots))
     shapes = [(int(rng.choice([1, 2, 3, 7, 8, 9, 16, 17, 31, 33, 50, 64, 65, 100, 130])),
                int(rng.choice([1, 5, 64, 255, 256, 257, 770, 1537]))) for _ in range(40)]
     b, units = _tall_batch(rng, shapes, [0.0, 0.002, 0.02, 0.3])
     plan = scan.Plan(b.pack()[1])
-    assert 0 < plan.rows_per_chunk <= max(rows_per_chunk, 8)
+    assert 0 < plan.rows_per_chunk <= max(rows_per_chunk or 48, 8)
     plan.close()
     out = scan.scan_batch(b, want_pos=True)
     for i, (m, rows, cds) in enumerate(units):
@@ -240,7 +242,8 @@ def test_unit_at_the_row_limit(gpu):
     assert out.sfs(0).tolist() == o["sfs"].tolist()
 
 
-@pytest.mark.parametrize("rows_per_chunk,slots,seed", [(8, 16, 0), (12, 64, 1), (36, 64, 2), (8, 256, 3), (64, 32, 4)])
+@pytest.mark.parametrize("rows_per_chunk,slots,seed", [(8, 16, 0), (12, 64, 1), (36, 64, 2), (8, 256, 3), (64, 32, 4),
+                                                       (None, 64, 5), (None, 16, 6), (None, 64, 7)])
 def test_tall_kernel_coding_forced_on_small_units(gpu, monkeypatch, rows_per_chunk, slots, seed):
     """The coding variant of the row-chunked kernel forced onto units of any size, with tiny chunks
     (columns turn joint in early, middle and late chunks: codon slots seeded from count slots in
@@ -249,7 +252,8 @@ def test_tall_kernel_coding_forced_on_small_units(gpu, monkeypatch, rows_per_chu
     (unclean codons), lengths that are not multiples of 3 or 256 (columns straddling tiles), row
     subsets in any order."""
     monkeypatch.setenv("PFA_TALL_MIN", "0")
-    monkeypatch.setenv("PFA_TALL_ROWS", str(rows_per_chunk))
+    if rows_per_chunk is not None:      # None: the plan's own 48-row chunks (straight-line code) and a shorter last one
+        monkeypatch.setenv("PFA_TALL_ROWS", str(rows_per_chunk))
     monkeypatch.setenv("PFA_TALL_SLOTS", str(slots))
     rng = np.random.default_rng(500 + seed)
     b = scan.Batch(stride_align=int(rng.choice([16, 128])))
@@ -267,7 +271,7 @@ def test_tall_kernel_coding_forced_on_small_units(gpu, monkeypatch, rows_per_chu
             b.add_unit(mid, rows=rows, cds=True)
             units.append((m, rows, True))
     plan = scan.Plan(b.pack()[1])
-    assert 0 < plan.rows_per_chunk <= max(rows_per_chunk, 8)
+    assert 0 < plan.rows_per_chunk <= max(rows_per_chunk or 48, 8)
     plan.close()
     out = scan.scan_batch(b, want_pos=True, want_sn=True)
     for i, (m, rows, cds) in enumerate(units):
