@@ -6,9 +6,6 @@
 // getvarCDSsites :284-315 (no row limit there).
 #include "pfa_kernels.h"
 #include "pfa_launch.h"
-#ifndef PFA_TALL_PROBE
-#define PFA_TALL_PROBE 0
-#endif
 
 namespace pfa {
 
@@ -269,10 +266,6 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       wave_lds_sync();
-#if PFA_TALL_PROBE == 1
-      if (r0 + R < N) stage_chunk(tile, r0 + R, idx_cur); else if (tile + 1u < t1) stage_chunk(tile + 1u, 0u, idx_cur);
-      continue;
-#endif
       if (cds && r0 == 0u && tile > t0) {
         // H of the previous tile's last two sites, for the codons that straddle into this tile
         if (lane < 2u) hsite[(int)lane - 2] = hsite[TW - 2u + lane];
@@ -359,7 +352,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
       wave_lds_sync();
 
       // ---------------- coding units: columns that turn joint in this chunk get a codon slot
-      if (cds && any_new && PFA_TALL_PROBE != 4) {   // a column can only turn joint in a chunk in which one of its sites turns variable
+      if (cds && any_new) {   // a column can only turn joint in a chunk in which one of its sites turns variable
         uint64_t jb_now[2];
         joint_ballots(nvd, jb_now);
 #pragma unroll
@@ -379,10 +372,6 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
         wave_lds_sync();
       }
 
-#if PFA_TALL_PROBE == 2
-      if (r0 + R < N) stage_chunk(tile, r0 + R, idx_cur); else if (tile + 1u < t1) stage_chunk(tile + 1u, 0u, idx_cur);
-      continue;
-#endif
       // ---------------- tier 2: the chunk's rows of every slotted site
       const uint32_t slot16 = lane >> 2, ph = lane & 3u;
       const uint32_t rows_after = r0 + Rc;
@@ -401,9 +390,13 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
             const uint8_t* q = colp + ph * TW;
             if (Rc == RF) {
               static_assert(RF == 48u, "twelve reads per lane below");
+              // The twelve bytes of this lane: all reads in flight and one wait (see tier 1), packed four to a word and compared
+              // with x and with y byte-parallel: a byte of w ^ xxxx is zero where the row holds x (12 compares + 12 adds per
+              // value otherwise).  (d16 loads, which deliver two bytes per register, cost more than the packing they save:
+              // 0.79 -> 0.69 at N = 1 000.)
               uint32_t v[12];
               const uint32_t at = (uint32_t)(uintptr_t)q;
-              asm volatile(   // the twelve reads in flight, one wait (see tier 1)
+              asm volatile(
                   "ds_read_u8 %0, %12\n\tds_read_u8 %1, %12 offset:1024\n\tds_read_u8 %2, %12 offset:2048\n\t"
                   "ds_read_u8 %3, %12 offset:3072\n\tds_read_u8 %4, %12 offset:4096\n\tds_read_u8 %5, %12 offset:5120\n\t"
                   "ds_read_u8 %6, %12 offset:6144\n\tds_read_u8 %7, %12 offset:7168\n\tds_read_u8 %8, %12 offset:8192\n\t"
@@ -413,11 +406,16 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
                     "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11])
                   : "v"(at)
                   : "memory");
+              const uint32_t x4 = __builtin_amdgcn_perm(0u, x, 0u), y4 = __builtin_amdgcn_perm(0u, y, 0u);   // the byte in all four
+              uint32_t nx = 0u, ny = 0u;   // rows that do not hold x / y
 #pragma unroll
-              for (uint32_t i = 0; i < 12u; ++i) {
-                c1 += (v[i] == x);
-                c2 += (v[i] == y);
+              for (uint32_t j = 0; j < 3u; ++j) {
+                const uint32_t w = (v[4u * j] | v[4u * j + 1u] << 16) | (v[4u * j + 2u] | v[4u * j + 3u] << 16) << 8;
+                nx += (uint32_t)__builtin_popcount(byte_nonzero_bits(w ^ x4));
+                ny += (uint32_t)__builtin_popcount(byte_nonzero_bits(w ^ y4));
               }
+              c1 = 12u - nx;
+              c2 = 12u - ny;
             } else {
               const uint32_t n4 = Rc >> 2;
 #pragma unroll 4
@@ -483,12 +481,17 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
         }
       }
       // ---------------- coding units: the chunk's rows of every codon slot (one row per lane)
-      for (uint32_t k = 0; k < ncs && PFA_TALL_PROBE != 3; ++k) {
+      for (uint32_t k = 0; k < ncs; ++k) {
         const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(cs_end[k] - 2);
         const uint8_t* q = tile8 + lane * TW + first;
-        const uint32_t b0 = q[0], b1 = q[1], b2 = q[2];
-        const unsigned long long M = wave_or_uniform(lane < Rc ? codon_bit(b0, b1, b2) : 0ull);
-        if (lane == 0u) cs_set[k] |= M;   // (64 lanes OR-ing into the word with an LDS atomic: 0.70 -> 0.49 at N = 1 000)
+        const uint32_t w = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16;
+        // three bytes at once: 2-bit codes, the letters those codes stand for, and whether they are the bytes read
+        const uint32_t codes = (w >> 1) & 0x030303u;
+        const bool ok = __builtin_amdgcn_perm(0u, 0x47544341u, codes | 0x0C000000u) == w && lane < Rc;
+        const uint32_t idx = ((codes << 4) | (codes >> 6) | (codes >> 16)) & 63u;
+        // (the set as a ballot of the lanes that a ds_permute of 1s to lane `idx` reaches: no faster than the DPP OR)
+        const unsigned long long M = wave_or_uniform(ok ? 1ull << idx : 0ull);
+        if (lane == 0u) cs_set[k] |= M;
       }
       wave_lds_sync();   // the tile buffer has been read for the last time
       idx_cur = idx_nxt;

@@ -3,7 +3,7 @@
 # usage: tools/bench_tall.sh [tag] [other libpfa_hip .so]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/tall_${1:-x}.txt
-OTHER="$2 $3"
+OTHER="$2 $3 $4"
 : > $OUT
 one() {
   local label=$1; shift
