@@ -408,7 +408,9 @@ typedef struct pfa_ingest_batch {
   const uint32_t* unit_key;  /* [n_units] key index, PFA_NO_KEY without --pops */
   const uint32_t* unit_rows; /* [n_units] N of the unit */
   const uint32_t* bad_bytes; /* [n_files] nonzero once the plan has been fetched: bytes >= 0x80 in
-                                sequence lines (that file is PFA_FILE_UNSUPPORTED) */
+                                sequence lines (that file is PFA_FILE_UNSUPPORTED; a file whose records differ
+                                in BYTE length and hold such bytes has that status already: the reference counts
+                                characters, PolyFastA.py:239-245, and the caller reads such files as text) */
   pfa_plan* plan;            /* already launched; NULL when n_units == 0; owned by the ingest */
 } pfa_ingest_batch;
 

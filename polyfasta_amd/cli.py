@@ -205,6 +205,68 @@ def _attach(pending, out, done, want_sfs=False):
             done.append(ev)
 
 
+def read_text_alignment(lines):
+    """The reference's reader on text lines, call for call (PolyFastA.py:231-236 / :240-245): a character is a site whatever
+    its UTF-8 length, `.upper()` is Unicode's (one sharp s becomes two letters) and `.rstrip()` strips Unicode white space.
+    Returns the dict header -> sequence, or None where the reference returns 1 (no header line)."""
+    data = {}
+    head = ""
+    for line in lines:
+        if line[0] == ">":
+            head = line[1:].rstrip()
+            data[head] = ""
+        elif len(head) != 0 and line[0] != ">":
+            data[head] += line.rstrip().upper()
+    return None if head == "" else data
+
+
+def text_alignment_units(data, path, args, keys):
+    """A file whose sequence lines hold non-ASCII characters (the native loader keeps one byte per base and hands such files back),
+    from the reference's own reading of it (`read_text_alignment`): every distinct non-ASCII character gets a byte value of
+    its own — the scan only asks whether two rows hold the same symbol and whether a symbol is exactly A, C, G or T — and
+    the matrix is scanned on the card as one small batch.  Returns (units, lines): units as (key index or PFA_NO_KEY,
+    n_rows, n_sites, record, syn row, sfs list), lines as (sub-order, kind, text); or None when the file holds more than
+    128 distinct non-ASCII characters or no sites."""
+    from ._lib import PFA_NO_KEY
+    name = path.split("/")[-1]
+    if data is None:
+        return [], [(0, "stdout", f"# file {path} is not FASTA!")]                                      # :247
+    names, seqs = list(data.keys()), list(data.values())
+    if len(set(len(x) for x in seqs)) != 1:
+        return [], [(0, "comment", f"# Sequences do not have the same length: {name}")]                # :135-140
+    seqlen = len(seqs[0])
+    others = sorted({c for x in seqs for c in x if ord(c) >= 0x80})
+    if len(others) > 128 or seqlen == 0:
+        return None
+    table = {ord(c): 0x80 + i for i, c in enumerate(others)}
+    m = np.frombuffer("".join(seqs).translate(table).encode("latin-1"), dtype=np.uint8).reshape(len(seqs), seqlen)
+    lines = []
+    if args.cds and seqlen % 3 != 0:                                                                    # :114-119
+        lines.append((0, "comment", f"# CDS sequence length is not a multiple of 3: {name}"))
+    batch = Batch(stride_align=128)
+    mid = batch.add_matrix(m)
+    heads = []
+    if not keys:
+        batch.add_unit(mid, cds=args.cds)
+        heads.append((PFA_NO_KEY, len(seqs)))
+    else:
+        for j, key in enumerate(keys):                                                                  # :123-134
+            rows = [i for i, h in enumerate(names) if key in h]
+            if not rows:
+                lines.append((1 + j, "comment", f"# Pop {key} string was not found in fasta headers."))
+                continue
+            batch.add_unit(mid, rows=np.asarray(rows, dtype=np.uint32), cds=args.cds)
+            heads.append((j, len(rows)))
+    units = []
+    if heads:
+        out = scan_batch(batch)
+        for i, (j, n_rows) in enumerate(heads):
+            bad = int(out.results[i]["sfs_bad"]) != 0
+            units.append((j, n_rows, seqlen, out.results[i], None if out.syn_num is None else out.syn_num[i],
+                          None if (bad or not args.sfs) else out.sfs(i).tolist()))
+    return units, lines
+
+
 def process_pipe(indexed_paths, args):
     """--pipe: one alignment from standard input (PolyFastA.py:96-100, 230-236), parsed by the
     native packer, scanned as one small batch; returns its output events."""
@@ -212,12 +274,28 @@ def process_pipe(indexed_paths, args):
     for fidx, path in indexed_paths:
         from ._lib import PFA_ERR_UNSUPPORTED, PfaError
         try:
-            aln = fasta.read_fasta_stdin(stride_align=128)
+            raw = sys.stdin.buffer.read()
+            aln = fasta.parse_fasta_bytes(raw, 128)
             status = PFA_FILE_NOT_FASTA if aln is None else (0 if aln.same_length else PFA_FILE_UNEQUAL)
         except PfaError as e:
             if e.code != PFA_ERR_UNSUPPORTED:
                 raise
             aln, status = None, PFA_FILE_UNSUPPORTED
+            import io
+            text = io.TextIOWrapper(io.BytesIO(raw), encoding=getattr(sys.stdin, "encoding", None) or "utf-8",
+                                    errors=getattr(sys.stdin, "errors", None) or "strict")   # sys.stdin.readlines(), :231
+            keys = args.pops.split(",") if args.pops else []
+            got = text_alignment_units(read_text_alignment(text), path, args, keys)
+            if got is not None:      # non-ASCII characters in sequence lines: read as text, the way the reference reads it
+                from ._lib import PFA_NO_KEY
+                name = path.split("/")[-1]
+                items = [(sub, 0, (fidx, kind, line)) for sub, kind, line in got[1]]
+                items += [(0 if j == PFA_NO_KEY else 1 + j, 1,
+                           (fidx, "unit", name, "NA" if j == PFA_NO_KEY else keys[j], n_rows, seqlen, tuple(rec.tolist()), syn, sfs))
+                          for j, n_rows, seqlen, rec, syn, sfs in got[0]]
+                items.sort(key=lambda t: t[:2])
+                done.extend(t[2] for t in items)
+                continue
         batch = Batch(stride_align=128)
         mid = batch.add_matrix(aln.matrix) if status == 0 else None
         pending = _events_for(fidx, path, path.split("/")[-1], status, aln.names if aln else None,
@@ -430,6 +508,7 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
     meta["n_rows"] = b.unit_rows
     meta["n_sites"] = b.n_sites[b.unit_file]
     specials = []
+    extra = []      # rows of files read as text (non-ASCII sequence characters)
     keep = None
     bad = b.bad != 0 if b.bad is not None and len(b.bad) else np.zeros(b.n_files, dtype=bool)
     if not b.regular or bad.any():
@@ -438,6 +517,7 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
             path = paths[int(b.file_idx[int(np.flatnonzero(st == PFA_ERR_IO)[0])])]
             open(path, "rb").close()          # raises the OSError the reference would raise (PolyFastA.py:239)
             raise OSError(f"cannot read {path}")
+        bad = bad | (st == PFA_FILE_UNSUPPORTED)      # unequal BYTE lengths and non-ASCII characters: the loader could not tell
         odd = (st != 0) | bad
         if args.cds:
             odd |= (st == 0) & (b.n_sites % 3 != 0)
@@ -451,8 +531,18 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
                 specials.append((fidx, 0, "stdout", f"# file {path} is not FASTA!"))                        # :247 (always stdout)
             elif st[k] == PFA_FILE_UNEQUAL:
                 specials.append((fidx, 0, "comment", f"# Sequences do not have the same length: {name}"))   # :135-140
-            elif bad[k]:    # this file only: the rest of the batch is scanned (deviations)
-                specials.append((fidx, 0, "comment", f"# Sequences hold non-ASCII characters (not supported, one byte per base): {name}"))
+            elif bad[k]:    # non-ASCII characters in sequence lines: this file is read as text, the way the reference reads it
+                got = None
+                try:
+                    with open(path, "r") as fh:                                                              # :239
+                        got = text_alignment_units(read_text_alignment(fh), path, args, keys)
+                except UnicodeDecodeError:      # not text in the locale's encoding (the reference dies with this error here)
+                    pass
+                if got is None:
+                    specials.append((fidx, 0, "comment", f"# Sequences hold non-ASCII characters (not supported, one byte per base): {name}"))
+                else:
+                    extra.extend((fidx,) + u for u in got[0])
+                    specials.extend((fidx,) + x for x in got[1])
             else:
                 if args.cds and int(b.n_sites[k]) % 3 != 0:                                                  # :114-119
                     specials.append((fidx, 0, "comment", f"# CDS sequence length is not a multiple of 3: {name}"))
@@ -471,6 +561,18 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
         meta, res = meta[keep], res[keep]
         syn = None if syn is None else syn[keep]
         sfs = None if sfs is None else [x for x, k in zip(sfs, keep.tolist()) if k]
+    if extra:
+        from ._lib import PFA_SYN_BINS
+        em = np.zeros(len(extra), dtype=META_DTYPE)
+        em["fidx"], em["key"] = [u[0] for u in extra], [u[1] for u in extra]
+        em["n_rows"], em["n_sites"] = [u[2] for u in extra], [u[3] for u in extra]
+        meta = np.concatenate([meta, em])
+        res = np.concatenate([res, np.array([u[4] for u in extra], dtype=res.dtype)])
+        if args.cds:
+            more = np.array([u[5] for u in extra], dtype=np.uint32).reshape(-1, PFA_SYN_BINS)
+            syn = more if syn is None else np.concatenate([syn, more])
+        if args.sfs:
+            sfs = (sfs or []) + [u[6] for u in extra]
     return RowBlock(meta, res, syn, sfs, specials)
 
 

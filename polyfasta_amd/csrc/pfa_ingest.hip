@@ -487,6 +487,16 @@ void worker_body(pfa_ingest* g) {
           f.n_sites = n ? rows[0].seq_len : 0u;
           for (const pfa_fasta_row& r : rows)
             if (r.seq_len != f.n_sites) { f.status = PFA_FILE_UNEQUAL; break; }   // PolyFastA.py:111-112
+          if (f.status == PFA_FILE_UNEQUAL) {
+            // byte lengths say nothing about a file whose sequences hold non-ASCII characters (the reference counts
+            // characters): hand it back as such, the caller reads it as text
+            for (const pfa_fasta_row& r : rows) {
+              const uint8_t* q = text.data() + r.seq_off;
+              bool high = false;
+              for (size_t i = 0; i < r.seq_len && !high; ++i) high = q[i] >= 0x80u;
+              if (high) { f.status = PFA_FILE_UNSUPPORTED; break; }
+            }
+          }
           if (f.status == 0) {
             // the rows in transport form, each on a 16-byte boundary: two bits per base when the row is
             // clean A/C/G/T, its bytes otherwise

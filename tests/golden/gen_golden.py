@@ -15,7 +15,8 @@ tests/golden/example_theta_0.01/ATTRIBUTION).
 
 Families: G1 examples, G2 synthetic grid, G3 odd symbols and
 FASTA syntax, G4 exhaustive codon-set tables, G5 coding alignments, G6
-populations, G7 command-line transcripts, G8 the BASELINE.json configurations
+populations, G7 command-line transcripts, G8 the BASELINE.json configurations, G9 sequences with
+non-ASCII characters
 at their full sizes.
 """
 import contextlib
@@ -463,7 +464,77 @@ def g8():
     dump("g8_baseline_configs.json", out)
 
 
+# ------------------------------------------------------- G9 sequences with non-ASCII characters
+def g9_texts():
+    """Small alignments whose SEQUENCE lines hold non-ASCII characters: the reference reads text (`open(file, 'r')`), so a
+    character is a site whatever its UTF-8 length, `.upper()` is Unicode's (it turns one sharp s into two letters) and
+    `.rstrip()` strips Unicode white space (PolyFastA.py:238-245)."""
+    rnd = random.Random(99)
+    base = "".join(rnd.choice("ACGT") for _ in range(60))
+
+    def mutate(s, k):
+        s = list(s)
+        for _ in range(k):
+            i = rnd.randrange(len(s))
+            s[i] = rnd.choice("ACGT")
+        return "".join(s)
+
+    rows = [mutate(base, k) for k in (0, 2, 3, 1, 4, 2)]
+    t = {}
+    # accented letters in some rows at some sites (lower case: upper() applies), names with non-ASCII too
+    a = [list(r) for r in rows]
+    a[1][7] = "\u00e9"
+    a[2][7] = "\u00c9"      # the same letter after upper()
+    a[3][20] = "\u00f1"
+    a[4][20] = "\u00e9"
+    a[5][33] = "\u0416"     # Cyrillic, two bytes
+    a[0][41] = "\u20ac"     # three bytes
+    a[2][41] = "\U0001F9EC"  # four bytes
+    t["accents"] = "".join(f">pop{1 + i % 2}_s{i}_\u00fc\n{''.join(r[:30])}\n{''.join(r[30:]).lower()}\n" for i, r in enumerate(a))
+    # sharp s in every row at the same site: every sequence grows by one character (61 sites)
+    b = [list(r) for r in rows]
+    for r in b:
+        r[10] = "\u00df"
+    t["sharp_s_all"] = "".join(f">s{i}\n{''.join(r).lower()}\n" for i, r in enumerate(b))
+    # sharp s in one row only: unequal lengths after upper()
+    c = [list(r) for r in rows]
+    c[3][10] = "\u00df"
+    t["sharp_s_one"] = "".join(f">s{i}\n{''.join(r).lower()}\n" for i, r in enumerate(c))
+    # Unicode white space at the end of sequence lines (stripped), and inside one (kept: a site)
+    d = ["".join(r) for r in rows]
+    t["unicode_space"] = "".join(f">s{i}\n{r[:30]}\u00a0\n{r[30:45]}\u2003{r[45:]}\u3000 \n" for i, r in enumerate(d))
+    return t
+
+
+def g9():
+    tmp = tempfile.mkdtemp()
+    texts = g9_texts()
+    for name, text in texts.items():
+        with open(os.path.join(tmp, name + ".fa"), "w", encoding="utf-8", newline="") as fh:
+            fh.write(text)
+    out = {"_texts": texts, "runs": {}}
+    runs = {"dir": ["-d", tmp], "dir_cds_jc": ["-d", tmp, "--cds", "--jc"]}
+    for name, args in runs.items():
+        p = subprocess.run([sys.executable, os.path.join(REF_DIR, "PolyFastA.py")] + args, capture_output=True,
+                           env={**os.environ, "PYTHONHASHSEED": "0", "PYTHONUTF8": "1"})
+        out["runs"][name] = {"args": [a.replace(tmp, "{TMP}") for a in args], "stdout": p.stdout.decode("utf-8").replace(tmp + "/", "{TMP}/"),
+                             "returncode": p.returncode}
+    # populations (the reference's own --pops fails under Python 3, `len(filter)`; its functions on the split it intends, as G6 does)
+    d = ref.readfasta(os.path.join(tmp, "accents.fa"), False)
+    seqlen = len(next(iter(d.values())))
+    out["pops"] = {}
+    for key in ("pop1", "pop2", "\u00fc", "absent"):
+        grp = {h: s for h, s in d.items() if key in h}
+        if not grp:
+            out["pops"][key] = None
+            continue
+        for cds in (False, True):
+            out["pops"][f"{key}|cds={int(cds)}"] = capture(ref.print_result, grp, seqlen, cds, "", "a", "accents.fa", key, True, 0, False).rstrip("\n")
+    shutil.rmtree(tmp)
+    dump("g9_unicode.json", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

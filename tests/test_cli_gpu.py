@@ -183,7 +183,8 @@ def test_ingest_repacks_any_text_like_the_reference_reader(gpu, tmp_path):
     (tmp_path / "t99_bad.fa").write_bytes(b">a\nAC\xc3\xb1T\n>b\nACGTT\n")
     rc, out = run_cli(["-d", str(tmp_path), "-s"])
     lines = out.rstrip("\n").split("\n")
-    assert lines[-1] == "# Sequences hold non-ASCII characters (not supported, one byte per base): t99_bad.fa"
+    # a non-ASCII character in a sequence line: read as text like the reference (4 characters against 5)
+    assert lines[-1] == "# Sequences do not have the same length: t99_bad.fa"
     assert len(lines) - 1 == len(want)
     for ln, name in zip(lines[:-1], sorted(want)):
         if want[name] is None:
@@ -241,3 +242,43 @@ def test_directory_listed_by_the_library_in_the_reference_order(gpu, tmp_path):
     assert ingest.Ingest.from_dir(str(tmp_path)) is None
     ing = ingest.Ingest.from_dir(str(tmp_path.parent / "no_such_directory"))
     assert ing is None
+
+
+def test_sequences_with_non_ascii_characters(gpu, tmp_path, monkeypatch):
+    """G9: the reference reads text, so a character is a site whatever its UTF-8 length, upper() is Unicode's (a sharp s
+    becomes two letters: lengths change) and rstrip() strips Unicode white space.  The native loader hands such files back
+    and the command line reads them as the reference does; the scan still runs on the card."""
+    g9 = C.load("g9_unicode.json")
+    d = tmp_path / "u"
+    d.mkdir()
+    for name, text in g9["_texts"].items():
+        (d / f"{name}.fa").write_bytes(text.encode("utf-8"))
+    # two plain files around them, so that the batch mixes both kinds
+    p = synth.make_params(8, 0.02)
+    for k, name in enumerate(("aaa_first", "zzz_last")):
+        (d / f"{name}.fa").write_text(synth.to_fasta_text(synth.headers_for(8), synth.synth_alignment(3, k, 60, p)))
+    for run, extra in (("dir", []), ("dir_cds_jc", ["--cds", "--jc"])):
+        rc, out = run_cli(["-d", str(d)] + extra)
+        assert rc == 0
+        lines = [ln for ln in out.split("\n") if not ln.startswith(("aaa_first.fa", "zzz_last.fa"))]
+        assert len(lines) + 2 == len(out.split("\n"))
+        same_transcript("\n".join(lines), g9["runs"][run]["stdout"].replace("{TMP}", str(d)))
+    # populations: rows of the reference's print_result on the split it intends; a key that is itself non-ASCII; a missing key
+    for cds in (0, 1):
+        rc, out = run_cli(["-f", str(d / "accents.fa"), "-p", "pop1,pop2,\u00fc,absent", "-s"] + (["--cds"] if cds else []))
+        want = [g9["pops"][f"{k}|cds={cds}"] for k in ("pop1", "pop2", "\u00fc")] + ["# Pop absent string was not found in fasta headers."]
+        got = [ln for ln in out.split("\n") if ln]
+        assert len(got) == len(want), out
+        for a, b in zip(got, want):
+            if a != b:
+                C.rows_close(a, b, rel=1e-9, rel_jc=1e-6, jc=False)
+    # --pipe: the same statistics as the file's row
+    rc, out = run_cli(["--pipe", "-s"], stdin_bytes=g9["_texts"]["accents"].encode("utf-8"), monkeypatch=monkeypatch)
+    want = [ln for ln in g9["runs"]["dir"]["stdout"].split("\n") if ln.startswith("accents.fa")][0]
+    got = [ln for ln in out.split("\n") if ln][0]
+    assert got.split(",")[1:5] == want.split(",")[1:5]
+    C.rows_close("x," + got.split(",", 1)[1], "x," + want.split(",", 1)[1], rel=1e-9, rel_jc=1e-6, jc=False)
+    # not text at all (a lone continuation byte): the reference dies with a UnicodeDecodeError; here the file gets a comment line
+    (d / "broken.fa").write_bytes(b">a\nAC\x80T\n>b\nACGT\n")
+    rc, out = run_cli(["-f", str(d / "broken.fa"), "-s"])
+    assert out.strip() == "# Sequences hold non-ASCII characters (not supported, one byte per base): broken.fa"

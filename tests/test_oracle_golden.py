@@ -144,3 +144,26 @@ def test_baseline_configs_g8():
                 assert (o["seg_S"], o["seg_N"], o["nstops"]) == (int(f[5]), int(f[6]), int(f[13]))
             else:
                 assert o["S"] == int(f[4])
+
+
+def test_unicode_sequences_g9(tmp_path):
+    """sequences with non-ASCII characters: the oracle's reader is the reference's (text mode), rows against the reference's CLI"""
+    g9 = C.load("g9_unicode.json")
+    for run, cds, jc in (("dir", False, False), ("dir_cds_jc", True, True)):
+        rows = {ln.split(",")[0]: ln for ln in g9["runs"][run]["stdout"].split("\n") if ln and not ln.startswith(("#", "file,"))}
+        for name, text in g9["_texts"].items():
+            p = tmp_path / f"{name}.fa"
+            p.write_bytes(text.encode("utf-8"))
+            d = orc.readfasta(str(p))
+            lens = {len(x) for x in d.values()}
+            if len(lens) != 1:
+                assert f"{name}.fa" not in rows
+                continue
+            C.rows_close(orc.result_row(d, lens.pop(), cds, f"{name}.fa", "NA", jc), rows[f"{name}.fa"], rel=1e-12, rel_jc=1e-9, jc=jc)
+    d = orc.readfasta(str(tmp_path / "accents.fa"))
+    for key, row in g9["pops"].items():
+        if row is None:
+            assert not orc.split_pop(d, key)
+            continue
+        k, cds = key.split("|cds=")
+        C.rows_close(orc.result_row(orc.split_pop(d, k), 60, bool(int(cds)), "accents.fa", k, False), row, rel=1e-12)
