@@ -92,11 +92,25 @@ def no_var():
 def readfasta(file, stdin):
     """dict header -> upper-case sequence, or 1 (after printing the reference's
     message) when the input is not FASTA."""
-    aln = fasta.read_fasta_stdin() if stdin else fasta.read_fasta_file(file)
-    if aln is None:
+    from ._lib import PFA_ERR_UNSUPPORTED, PfaError
+    import io
+    import sys
+    raw = sys.stdin.buffer.read() if stdin else None
+    try:
+        aln = fasta.parse_fasta_bytes(raw) if stdin else fasta.read_fasta_file(file)
+        d = None if aln is None else aln.to_dict()
+    except PfaError as e:       # non-ASCII characters in sequence lines: the reference's own text reading (a character is a site)
+        if e.code != PFA_ERR_UNSUPPORTED:
+            raise
+        if stdin:
+            d = fasta.read_text_alignment(io.TextIOWrapper(io.BytesIO(raw), encoding=getattr(sys.stdin, "encoding", None) or "utf-8"))
+        else:
+            with open(file, "r") as fh:
+                d = fasta.read_text_alignment(fh)
+    if d is None:
         print(f"# file {file} is not FASTA!")
         return 1
-    return aln.to_dict()
+    return d
 
 
 def getvarsites(d, seqlen):

@@ -205,24 +205,9 @@ def _attach(pending, out, done, want_sfs=False):
             done.append(ev)
 
 
-def read_text_alignment(lines):
-    """The reference's reader on text lines, call for call (PolyFastA.py:231-236 / :240-245): a character is a site whatever
-    its UTF-8 length, `.upper()` is Unicode's (one sharp s becomes two letters) and `.rstrip()` strips Unicode white space.
-    Returns the dict header -> sequence, or None where the reference returns 1 (no header line)."""
-    data = {}
-    head = ""
-    for line in lines:
-        if line[0] == ">":
-            head = line[1:].rstrip()
-            data[head] = ""
-        elif len(head) != 0 and line[0] != ">":
-            data[head] += line.rstrip().upper()
-    return None if head == "" else data
-
-
 def text_alignment_units(data, path, args, keys):
     """A file whose sequence lines hold non-ASCII characters (the native loader keeps one byte per base and hands such files back),
-    from the reference's own reading of it (`read_text_alignment`): every distinct non-ASCII character gets a byte value of
+    from the reference's own reading of it (`fasta.read_text_alignment`): every distinct non-ASCII character gets a byte value of
     its own — the scan only asks whether two rows hold the same symbol and whether a symbol is exactly A, C, G or T — and
     the matrix is scanned on the card as one small batch.  Returns (units, lines): units as (key index or PFA_NO_KEY,
     n_rows, n_sites, record, syn row, sfs list), lines as (sub-order, kind, text); or None when the file holds more than
@@ -235,10 +220,9 @@ def text_alignment_units(data, path, args, keys):
     if len(set(len(x) for x in seqs)) != 1:
         return [], [(0, "comment", f"# Sequences do not have the same length: {name}")]                # :135-140
     seqlen = len(seqs[0])
-    others = sorted({c for x in seqs for c in x if ord(c) >= 0x80})
-    if len(others) > 128 or seqlen == 0:
+    table = fasta.byte_codes(seqs)
+    if table is None or seqlen == 0:
         return None
-    table = {ord(c): 0x80 + i for i, c in enumerate(others)}
     m = np.frombuffer("".join(seqs).translate(table).encode("latin-1"), dtype=np.uint8).reshape(len(seqs), seqlen)
     lines = []
     if args.cds and seqlen % 3 != 0:                                                                    # :114-119
@@ -285,7 +269,7 @@ def process_pipe(indexed_paths, args):
             text = io.TextIOWrapper(io.BytesIO(raw), encoding=getattr(sys.stdin, "encoding", None) or "utf-8",
                                     errors=getattr(sys.stdin, "errors", None) or "strict")   # sys.stdin.readlines(), :231
             keys = args.pops.split(",") if args.pops else []
-            got = text_alignment_units(read_text_alignment(text), path, args, keys)
+            got = text_alignment_units(fasta.read_text_alignment(text), path, args, keys)
             if got is not None:      # non-ASCII characters in sequence lines: read as text, the way the reference reads it
                 from ._lib import PFA_NO_KEY
                 name = path.split("/")[-1]
@@ -535,7 +519,7 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
                 got = None
                 try:
                     with open(path, "r") as fh:                                                              # :239
-                        got = text_alignment_units(read_text_alignment(fh), path, args, keys)
+                        got = text_alignment_units(fasta.read_text_alignment(fh), path, args, keys)
                 except UnicodeDecodeError:      # not text in the locale's encoding (the reference dies with this error here)
                     pass
                 if got is None:

@@ -143,19 +143,45 @@ def read_fasta_stdin(stride_align: int = 16):
     return parse_fasta_bytes(sys.stdin.buffer.read(), stride_align)
 
 
+def read_text_alignment(lines):
+    """The reference's reader on text lines, call for call (PolyFastA.py:231-236 / :240-245): a character is a site whatever
+    its UTF-8 length, `.upper()` is Unicode's (one sharp s becomes two letters) and `.rstrip()` strips Unicode white space.
+    Returns the dict header -> sequence, or None where the reference returns 1 (no header line).  The native loader keeps
+    one byte per base and hands files with non-ASCII sequence characters back; they are read with this."""
+    data = {}
+    head = ""
+    for line in lines:
+        if line[0] == ">":
+            head = line[1:].rstrip()
+            data[head] = ""
+        elif len(head) != 0 and line[0] != ">":
+            data[head] += line.rstrip().upper()
+    return None if head == "" else data
+
+
+def byte_codes(seqs):
+    """str.translate table that gives every distinct non-ASCII character of `seqs` a byte value of its own (0x80 ...): the
+    scan only asks whether two rows hold the same symbol and whether a symbol is exactly A, C, G or T.  None when there
+    are more than 128 of them."""
+    others = sorted({c for x in seqs for c in x if ord(c) >= 0x80})
+    if len(others) > 128:
+        return None
+    return {ord(c): 0x80 + i for i, c in enumerate(others)}
+
+
 def matrix_from_dict(d, seqlen=None) -> np.ndarray:
     """uint8 [N, seqlen] from the reference's in-memory alignment (dict header ->
-    string).  Characters must fit one byte; a sequence shorter than `seqlen`
+    string).  Non-ASCII characters get byte values of their own (`byte_codes`); a sequence shorter than `seqlen`
     is padded with NUL, which plays the role of the empty slice ``''`` that the
     reference would see there (PolyFastA.py:256)."""
     seqs = list(d.values())
     if seqlen is None:
         seqlen = len(seqs[0]) if seqs else 0
+    table = byte_codes(s[:seqlen] for s in seqs)
+    if table is None:
+        raise ValueError("more than 128 distinct non-ASCII characters cannot be packed one byte per base")
     out = np.zeros((len(seqs), seqlen), dtype=np.uint8)
     for i, s in enumerate(seqs):
-        try:
-            b = s[:seqlen].encode("latin-1")
-        except UnicodeEncodeError as exc:
-            raise ValueError("characters above U+00FF cannot be packed one byte per base") from exc
+        b = s[:seqlen].translate(table).encode("latin-1")
         out[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
     return out

@@ -282,3 +282,12 @@ def test_sequences_with_non_ascii_characters(gpu, tmp_path, monkeypatch):
     (d / "broken.fa").write_bytes(b">a\nAC\x80T\n>b\nACGT\n")
     rc, out = run_cli(["-f", str(d / "broken.fa"), "-s"])
     assert out.strip() == "# Sequences hold non-ASCII characters (not supported, one byte per base): broken.fa"
+    # the API mirror on the same file: the reference's function names on a dict of text (PolyFastA.py:227-261, :502-520)
+    from oracle import polyfasta_oracle as orc
+    from polyfasta_amd import api
+    da, do = api.readfasta(str(d / "accents.fa"), False), orc.readfasta(str(d / "accents.fa"))
+    assert da == do and list(da) == list(do)
+    (pa, va), (po, vo) = api.getvarsites(da, 60), orc.getvarsites(do, 60)
+    assert pa == po and [list(c) for c in va] == [list(c) for c in vo]
+    for x, y in zip(api.polymorphism(va, 60, False), orc.polymorphism(vo, 60, False)):
+        assert x == y or abs(x - y) <= 1e-9 * abs(y)
