@@ -17,6 +17,9 @@
 // getvarCDSsites :284-315, get_syn_nonsyn_cod_sites :319-434.
 #include "pfa_kernels.h"
 #include "pfa_launch.h"
+#ifndef PFA_T2_WIDE
+#define PFA_T2_WIDE 1
+#endif
 
 namespace pfa {
 
@@ -268,7 +271,16 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
         }
       }
     };
-    tier2(std::integral_constant<uint32_t, 4u>{});
+    // 128-site tiles (units of 65 to about 200 rows) with few variable sites: 8 lanes per site halve the rows a lane walks and
+    // with them the dependent LDS round trips of the walk (N = 200 coding 0.722 -> 0.740, N = 200 0.776 -> 0.786; the 256-site
+    // tiles of units up to 64 rows have 16 rows per lane at most and more than 8 variable sites as a rule: nothing to gain)
+    bool wide_walk = false;
+    if constexpr (TWP == 128u && PFA_T2_WIDE) wide_walk = P <= 8u;
+    if (wide_walk) {
+      if constexpr (TWP == 128u && PFA_T2_WIDE) tier2(std::integral_constant<uint32_t, 8u>{});
+    } else {
+      tier2(std::integral_constant<uint32_t, 4u>{});
+    }
 
     // ---------------- coding sequences: the codon columns that END in this tile (CodonPass)
     if (cds) {
