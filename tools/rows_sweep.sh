@@ -13,7 +13,8 @@ one() {
   line=$(env "${ENVS[@]}" python3 $R/bench.py --no-cpu-baseline --no-extras --steps 16 --warmup 3 --rows $n --sites $sites --batch $b "$@" 2>/dev/null)
   echo "N=$n ${ENVS[*]} $* :: $(echo "$line" | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print("%.0f GB/s  frac %.3f  lds %d  %s" % (j["roofline"]["achieved"], j["roofline"]["frac"], j["config"]["lds_bytes_per_wave"], j["roofline"]["kernel"][:60]))')" >> $OUT
 }
-for n in 144 160 176 192 200 208 224 250 300; do
+python3 $R/bench.py --no-cpu-baseline --no-extras --steps 2000 --warmup 3 > /dev/null 2>&1   # (discarded warm-up)
+for n in 100 128 144 160 176 192 200 208 224 250 300; do
   ENVS=(PFA_X=1); one $n "$@"
   ENVS=(PFA_TALL_MIN=100); one $n "$@"
 done
