@@ -221,10 +221,33 @@ __attribute__((target("avx2"))) static bool pack2_avx2(const uint8_t* src, uint6
 }
 #endif
 
+#if defined(__x86_64__)
+// 64 bases per step: the same arithmetic on 512-bit registers, and the sixteen packed bytes leave through one
+// dword -> byte narrowing store instead of two extracts (pack2_row is three quarters of a loader thread's time after read())
+__attribute__((target("avx512f,avx512bw"))) static bool pack2_avx512(const uint8_t* src, uint64_t n, uint8_t* dst) {
+  const __m512i fold = _mm512_set1_epi8((char)0xDF), three = _mm512_set1_epi8(3);
+  const __m512i canon = _mm512_broadcast_i32x4(_mm_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0));
+  const __m512i w8 = _mm512_set1_epi16(0x0401), w16 = _mm512_set1_epi32(0x00100001);
+  __m512i bad = _mm512_setzero_si512();
+  uint64_t i = 0;
+  for (; i + 64 <= n; i += 64) {
+    const __m512i u = _mm512_and_si512(_mm512_loadu_si512(src + i), fold);
+    const __m512i c = _mm512_and_si512(_mm512_srli_epi16(u, 1), three);
+    bad = _mm512_or_si512(bad, _mm512_xor_si512(_mm512_shuffle_epi8(canon, c), u));
+    const __m512i t = _mm512_madd_epi16(_mm512_maddubs_epi16(c, w8), w16);        // one packed byte per 32-bit lane
+    _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + (i >> 2)), _mm512_cvtepi32_epi8(t));
+  }
+  const bool ok_tail = i == n || pack2_avx2(src + i, n - i, dst + (i >> 2));
+  return ok_tail && _mm512_test_epi8_mask(bad, bad) == 0;
+}
+#endif
+
 bool pack2_row(const uint8_t* src, uint64_t n, uint8_t* dst) {
 #if defined(__x86_64__)
-  static const bool have_avx2 = __builtin_cpu_supports("avx2");
-  if (have_avx2) return pack2_avx2(src, n, dst);
+  static const int level = __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512f") && !getenv("PFA_NO_AVX512") ? 2
+                           : __builtin_cpu_supports("avx2") ? 1 : 0;
+  if (level == 2) return pack2_avx512(src, n, dst);
+  if (level == 1) return pack2_avx2(src, n, dst);
 #endif
   return pack2_scalar(src, n, dst);
 }
