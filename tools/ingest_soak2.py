@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Randomised soak of the files -> rows path: directories of mixed files (clean A/C/G/T of every length modulo 64, lower case,
+other symbols, wrapped lines, CR / CRLF, unequal lengths, non-ASCII sequence characters), random loader threads and slot sizes;
+every row against the oracle (its reader on the same text, then the C scan).  usage: tools/ingest_soak2.py [seconds]"""
+import io, os, sys, tempfile, shutil, time
+from contextlib import redirect_stdout
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from polyfasta_amd import cli, fasta  # noqa: E402
+from oracle import c_oracle, polyfasta_oracle as orc  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+t_end = time.time() + budget
+seed = 0
+rows_checked = files_checked = 0
+while time.time() < t_end:
+    seed += 1
+    rng = np.random.default_rng(seed)
+    d = tempfile.mkdtemp(prefix="pfa_soak2_", dir="/dev/shm")
+    want = {}
+    try:
+        for i in range(int(rng.integers(3, 60))):
+            n = int(rng.choice([2, 3, 7, 12, 50, 65, 130]))
+            L = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 1000, 4097, 10000, 30011]))
+            base = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L)
+            seqs = []
+            for r in range(n):
+                s = base.copy()
+                k = int(rng.integers(0, max(1, L // 50) + 1))
+                if k:
+                    s[rng.integers(0, L, size=k)] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=k)
+                seqs.append(s.tobytes().decode())
+            kind = int(rng.integers(0, 8))
+            if kind == 1:
+                seqs = [x.lower() if rng.random() < 0.5 else x for x in seqs]
+            elif kind == 2:      # other symbols in some rows
+                for r in range(n):
+                    if rng.random() < 0.4:
+                        j = int(rng.integers(0, L))
+                        seqs[r] = seqs[r][:j] + str(rng.choice(list("N-nRY*"))) + seqs[r][j + 1:]
+            elif kind == 3 and L > 3:      # unequal lengths
+                seqs[-1] = seqs[-1][:-1]
+            elif kind == 4:      # non-ASCII characters (one per affected row, same site: lengths stay equal in characters)
+                j = int(rng.integers(0, L))
+                for r in range(n):
+                    if rng.random() < 0.5:
+                        seqs[r] = seqs[r][:j] + str(rng.choice(list("éÉñЖ€"))) + seqs[r][j + 1:]
+            eol = str(rng.choice(["\n", "\n", "\r\n", "\r"]))
+            wrap = int(rng.choice([0, 0, 60, 1000]))
+            text = ""
+            for r, x in enumerate(seqs):
+                body = eol.join(x[k:k + wrap] for k in range(0, len(x), wrap)) if wrap else x
+                text += f">s{r}_pop{1 + r % 2}{eol}{body}{eol}"
+            name = f"f{i:03d}.fa"
+            with open(os.path.join(d, name), "w", encoding="utf-8", newline="") as fh:
+                fh.write(text)
+            dd = orc.parse_fasta_lines(io.StringIO(text, newline=None))
+            if len({len(v) for v in dd.values()}) != 1:
+                want[name] = None
+            else:
+                o = c_oracle.scan(fasta.matrix_from_dict(dd))
+                want[name] = (len(next(iter(dd.values()))), len(dd), o["S"])
+        os.environ["PFA_THREADS"] = str(int(rng.choice([1, 3, 8, 16, 24])))
+        os.environ["PFA_INGEST_SLOT_BYTES"] = str(int(rng.choice([1 << 16, 1 << 20, 1 << 24])))
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            cli.main(["-d", d, "-s"])
+        lines = buf.getvalue().splitlines()
+        assert len(lines) == len(want), (seed, len(lines), len(want))
+        for ln, name in zip(lines, sorted(want)):
+            if want[name] is None:
+                assert ln == f"# Sequences do not have the same length: {name}", (seed, ln)
+            else:
+                f = ln.split(",")
+                assert f[0] == name and (int(f[1]), int(f[3]), int(f[4])) == want[name], (seed, ln, want[name])
+                rows_checked += 1
+        files_checked += len(want)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    if seed % 20 == 0:
+        print(f"seed {seed}: {files_checked} files, {rows_checked} rows identical", flush=True)
+print(f"ingest soak: {files_checked} files over {seed} directories, {rows_checked} rows identical to the oracle")
