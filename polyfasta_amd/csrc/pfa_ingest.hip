@@ -659,8 +659,9 @@ uint32_t auto_threads() {
   for (const char* var : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
     if (const char* e = getenv(var)) { const long v = strtol(e, nullptr, 10); if (v > 0) { ranks = (uint32_t)v; break; } }
   if (!getenv("PFA_CPUS_ARE_MINE")) local = ranks;
-  // measured (profiles/r03_e2e_thread_sweep.txt): 16 loaders 200-214 k alignments/s best / 176-204 k median; 20-24 reach 220 k in
-  // their best runs but swing down to 120-150 k on the same box; 28 and more collapse
+  // measured (profiles/r03_e2e_16_vs_20_vs_24_threads.txt, six alternating rounds): 16 loaders 219-230 k alignments/s best / 193-217 k
+  // median; 20: 217-249 k / 187-205 k; 24: 180-239 k / 170-190 k; 28 and more collapse (profiles/r03_e2e_thread_sweep.txt): the
+  // host's read() is capped in aggregate, more loaders only wait for ring slots
   return std::max(1u, std::min(16u, cpus / std::max(local, 1u)));
 }
 
