@@ -1,5 +1,5 @@
 """N > 1 host path on CPU: sharding, launcher, unique-id rendezvous, and a
-world_size-2 gloo job through the product's gather / merge code."""
+world_size-2 and -3 gloo jobs through the product's gather / merge code."""
 import json
 import os
 import socket
@@ -8,6 +8,8 @@ import sys
 import textwrap
 import threading
 import time
+
+import pytest
 
 from polyfasta_amd import dist
 
@@ -35,16 +37,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_gloo_gather(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_gloo_gather(tmp_path, world):
     out = tmp_path / "merged.json"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_dist_worker.py"), str(out), "23"]
     env = {**os.environ, "MASTER_ADDR": "127.0.0.1"}
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     res = json.load(open(out))
-    assert res["ok"] and res["world"] == 2 and res["tmax"] == 2.0 and res["n"] > 23
+    assert res["ok"] and res["world"] == world and res["tmax"] == float(world) and res["n"] > 23
 
 
 def test_unique_id_rendezvous_file(tmp_path, monkeypatch):
