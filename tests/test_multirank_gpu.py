@@ -40,8 +40,10 @@ def _single(argv):
     return buf.getvalue()
 
 
-@pytest.mark.parametrize("extra", [[], ["--cds", "--jc", "-p", "pop1,pop2"], ["--sfs", "-p", "pop2,nopop,pop1"]])
-def test_two_rank_cli_equals_single_process(gpu, tmp_path, extra):
+@pytest.mark.parametrize("extra,world", [([], 2), (["--cds", "--jc", "-p", "pop1,pop2"], 2), (["--sfs", "-p", "pop2,nopop,pop1"], 2),
+                                         ([], 3), (["--cds", "-p", "pop1,nopop"], 3)])
+def test_two_rank_cli_equals_single_process(gpu, tmp_path, extra, world):
+    """(two ranks, and three: uneven shares of the queue, two non-root ranks to merge on rank 0)"""
     d = _make_dir(tmp_path)
     argv = ["-d", str(d), "-s"] + extra
     want = _single(argv)
@@ -49,8 +51,8 @@ def test_two_rank_cli_equals_single_process(gpu, tmp_path, extra):
     out = tmp_path / "rank0.csv"
     port = dist._free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_cli_rank_worker.py"), str(out)] + argv,
                                       env=env, cwd=ROOT, stderr=subprocess.PIPE))
     for p in procs:
