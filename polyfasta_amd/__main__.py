@@ -4,27 +4,60 @@ import time
 
 _t_enter = time.time()          # wall clock: bench.py's cold_start leg subtracts its own spawn time
 
+
+def _launcher_only(argv):
+    """`--gpus N` with N > 1 and no launcher's environment: this process only starts the ranks (dist.spawn_ranks) and
+    must not touch the GPU itself."""
+    for i, a in enumerate(argv):
+        v = argv[i + 1] if a == "--gpus" and i + 1 < len(argv) else a[len("--gpus="):] if a.startswith("--gpus=") else None
+        if v is not None:
+            try:
+                return int(v) > 1
+            except ValueError:
+                return False
+    return False
+
+
 # A one-file run is dominated by start-up (interpreter, numpy, hipInit: bench.py `cold_start`).  The
 # HIP runtime is brought up by a native thread WHILE Python imports numpy and parses the command line;
-# pfa_init() joins it.  Ranks of a multi-GPU job bind their CPUs first and initialise in pfa_init().
-if "WORLD_SIZE" not in os.environ and not os.environ.get("PFA_NO_PREWARM"):
+# pfa_init() joins it.  Ranks of a multi-GPU job bind their CPUs first and initialise in pfa_init();
+# the launcher of `--gpus N` never initialises the GPU.
+_prewarmed = None
+if "WORLD_SIZE" not in os.environ and not os.environ.get("PFA_NO_PREWARM") and not _launcher_only(sys.argv[1:]):
     try:
         import ctypes
         _lib_path = os.environ.get("PFA_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpfa_hip.so")
-        ctypes.CDLL(_lib_path).pfa_prewarm(int(os.environ.get("LOCAL_RANK", "0")))
+        _prewarmed = ctypes.CDLL(_lib_path)
+        _prewarmed.pfa_prewarm(int(os.environ.get("LOCAL_RANK", "0")))
     except (OSError, AttributeError, ValueError):
-        pass        # cli.main() reports a missing library in its own words
+        _prewarmed = None        # cli.main() reports a missing library in its own words
 
 from . import cli  # noqa: E402
 
 cli.startup_marks.append(("interpreter+package+prewarm start", _t_enter))
 cli.startup_marks.append(("import cli (numpy, ctypes, argparse)", time.time()))
+rc = 1
 try:
     rc = cli.main()
 except SystemExit as e:         # argparse errors, --help
     rc = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
     if e.code is not None and not isinstance(e.code, int):
         print(e.code, file=sys.stderr)
+except KeyboardInterrupt:
+    rc = 130
+except BaseException:           # noqa: BLE001  the reference's way out of anything else: a traceback, exit code 1
+    import traceback
+    traceback.print_exc()
+    rc = 1
+finally:
+    # The prewarm thread may still be inside hipInit when main() ends before its first scan (closed stdin at the prompt,
+    # an unreadable directory, Ctrl-C): never leave the process under it — pfa_shutdown() joins it (and, on these paths
+    # only, tears the runtime down in order).  After a normal run pfa_init() has joined it long ago.
+    if _prewarmed is not None and rc != 0:
+        try:
+            _prewarmed.pfa_shutdown()
+        except Exception:       # noqa: BLE001
+            pass
 # every row has been written: leave without the interpreter's and the HIP runtime's teardown (45 ms of a
 # 0.3 s one-file run); the driver releases the device when the process is gone
 sys.stdout.flush()

@@ -180,6 +180,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+        # ranks of a multi-GPU job, whoever launched them (dist.spawn_ranks sets it too): RCCL's intra-node transport shares
+        # buffers through IPC handles and this pool's kernel driver only implements the dmabuf flavour — with the runtime's
+        # legacy default hipIpcGetMemHandle fails inside ncclCommInitRank.  Must be in the environment before the HIP
+        # runtime comes up (the first pfa_* call below); a value the user exported is kept.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not os.path.exists(LIB_PATH):
         raise PfaLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m polyfasta_amd._build` "

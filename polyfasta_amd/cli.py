@@ -667,6 +667,8 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
     from . import dist
     wq = dist.WorkQueue(len(paths), world) if world > 1 else None
     t_open = time.perf_counter() - t00
+    tm = {"next_wait_s": 0.0, "block_s": 0.0, "format_s": 0.0, "flags_gather_s": 0.0, "gather_s": 0.0, "gather_bytes": 0,
+          "root_merge_write_s": 0.0, "barrier_s": 0.0}      # stage timers of this rank (bench.py: end_to_end_ranks gathers them)
     if trace is not None:
         trace.append(("open", time.perf_counter() - t00, len(paths)))
     try:
@@ -708,6 +710,7 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
                     kept = [ready[1]]
                     emit_block(ready[0], sink, args, ing.table, paths, keys)
             t3 = time.perf_counter()
+            tm["next_wait_s"] += t1 - t0
             t_fetch += t2 - t1
             t_emit += t3 - t2
             if trace is not None:
@@ -718,28 +721,45 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
             # the number of ranks.  When some rank holds anything but plain rows (comment lines, --sfs, the progress chatter of
             # --out without --silent, a row the native formatter hands back) the blocks travel instead and rank 0 formats.
             import pickle
+            tg0 = time.perf_counter()
             mine = RowBlock.concat(kept, args.cds).sorted()
             runs = text_runs(mine, ing.table, args) if (not mine.specials and not args.sfs and sink.bulk_ok()) else None
-            flags = comm.all_gather_fixed(np.array([runs is not None], dtype=np.uint8))
+            tg1 = time.perf_counter()
+            flags = comm.all_gather_fixed(np.array([runs is not None], dtype=np.uint8))     # (also where a rank waits for the slowest one)
+            tg2 = time.perf_counter()
             if bool(flags.all()):
-                parts = comm.gather_bytes(pickle.dumps(runs, protocol=pickle.HIGHEST_PROTOCOL), dst=0)
+                blob = pickle.dumps(runs, protocol=pickle.HIGHEST_PROTOCOL)
+                tg3 = time.perf_counter()
+                parts = comm.gather_bytes(blob, dst=0)
+                tg4 = time.perf_counter()
                 if rank == 0:
                     allruns = sorted((r for p in parts for r in pickle.loads(p)), key=lambda r: r[0])
                     if allruns:
                         sink.rows("".join(r[1] for r in allruns))
             else:
-                parts = comm.gather_bytes(mine.to_bytes(), dst=0)
+                blob = mine.to_bytes()
+                tg3 = time.perf_counter()
+                parts = comm.gather_bytes(blob, dst=0)
+                tg4 = time.perf_counter()
                 if rank == 0:
                     allb = RowBlock.concat([RowBlock.from_bytes(p) for p in parts], args.cds).sorted()
                     emit_block(allb, sink, args, ing.table, paths, keys)
+            tg5 = time.perf_counter()
+            tm.update(format_s=(tg1 - tg0) + (tg3 - tg2), flags_gather_s=tg2 - tg1, gather_s=tg4 - tg3, gather_bytes=len(blob),
+                      root_merge_write_s=tg5 - tg4)
         if trace is not None:
             trace.append(("loop_end", time.perf_counter() - t00))
+        tb = time.perf_counter()
         if comm is not None:
             comm.barrier()
         t4 = time.perf_counter()
+        tm["barrier_s"] = t4 - tb
         sink.flush()
         st = ing.stats()
         st.update(files=len(paths), open_s=t_open, wall_s=time.perf_counter() - t00, fetch_wait_s=t_fetch, rows_s=t_emit, flush_s=time.perf_counter() - t4)
+        st.update(tm)
+        if wq is not None:
+            st.update(claims=wq.n_claims, claim_s=wq.claim_s, claimed_files=wq.n_items, queue_open_s=wq.open_s)
         last_stats.clear()
         last_stats.update(st)
         if trace is not None:
@@ -752,6 +772,7 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
         if wq is not None:
             wq.close(unlink=rank == 0)       # (success: every rank is past its last claim, the barrier above; failure: the others keep their descriptor)
         ing.close()
+        last_stats["close_s"] = time.perf_counter() - t9          # (queue descriptor, loader threads joined, buffers back in the cache)
         if trace is not None:
             print("PFA_TRACE close", round(time.perf_counter() - t9, 5), file=sys.stderr)
 
@@ -826,7 +847,9 @@ def main(argv=None, comm=None, close_comm=True):
     else:
         if os.environ.get("PFA_TRACE"):
             print("PFA_TRACE before_run_files", round(time.perf_counter() - t_main, 5), file=sys.stderr)
+        t_pre = time.perf_counter() - t_main
         run_files(paths, args, sink, rank, world, comm, keys, directory=args.dir if dir_mode else None)
+        last_stats["main_pre_s"] = t_pre                  # argparse, affinity, library, header (before the file loop)
         if os.environ.get("PFA_TRACE"):
             print("PFA_TRACE after_run_files", round(time.perf_counter() - t_main, 5), file=sys.stderr)
     mark("files -> rows (ingest, first kernel launches, fetch, print)")
@@ -837,6 +860,7 @@ def main(argv=None, comm=None, close_comm=True):
     if os.environ.get("PFA_TRACE_STARTUP"):
         import json
         print("PFA_STARTUP " + json.dumps(startup_marks), file=sys.stderr)
+    last_stats["main_s"] = time.perf_counter() - t_main
     return 0
 
 

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -261,12 +262,29 @@ static int init_impl(int device) {
 // its modules (tools/ubench/init_probe.hip: hipInit 50-230 ms, a stream = an HSA queue 20 ms, the first H2D copy 9 ms of SDMA
 // set-up, a translation unit's code object on its first launch): context, stream, the code objects of the scan / plan / ingest
 // kernels and the copy engine are up by the time Python has imported numpy.  pfa_init() waits for it.
-static std::thread g_prewarm;
+// (The thread object lives on the heap: a joinable std::thread in static storage would call std::terminate from the
+// library's static destructors when the interpreter exits before pfa_init() — an uncaught exception ahead of the first scan.)
+static std::thread* g_prewarm = nullptr;
+static std::mutex g_prewarm_mu;
+
+static void join_prewarm() {
+  std::thread* t = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_prewarm_mu);
+    t = g_prewarm;
+    g_prewarm = nullptr;
+  }
+  if (t) {
+    if (t->joinable()) t->join();
+    delete t;
+  }
+}
 
 void pfa_prewarm(int device) {
-  if (pfa::ctx().ready || g_prewarm.joinable()) return;
+  std::lock_guard<std::mutex> lk(g_prewarm_mu);
+  if (pfa::ctx().ready || g_prewarm) return;
   try {
-    g_prewarm = std::thread([device]() {
+    g_prewarm = new std::thread([device]() {
       if (init_impl(device) != PFA_OK) return;       // (pfa_init() repeats it on the caller's thread and reports the error there)
       hipFuncAttributes fa;
       (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(pfa::slab_to_host_kernel));
@@ -283,16 +301,17 @@ void pfa_prewarm(int device) {
       (void)hipGetLastError();
     });
   } catch (...) {
+    g_prewarm = nullptr;
   }
 }
 
 int pfa_init(int device) {
-  if (g_prewarm.joinable()) g_prewarm.join();
+  join_prewarm();
   return init_impl(device);
 }
 
 void pfa_shutdown(void) {
-  if (g_prewarm.joinable()) g_prewarm.join();
+  join_prewarm();
   pfa::Context& c = pfa::ctx();
   if (!c.ready) return;
   (void)hipStreamSynchronize(c.stream);

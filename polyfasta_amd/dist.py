@@ -92,6 +92,8 @@ class WorkQueue:
         # a claim = 1/(4 world) of the items at most: even a small directory is spread over the ranks
         self.grain = max(1, min(512, len(self.order) // (4 * self.world)))
         self.path = path or rendezvous_path() + ".queue"
+        self.n_claims, self.n_items, self.claim_s = 0, 0, 0.0           # this rank's claims (bench.py: the stage table of the N > 1 leg)
+        t0 = time.perf_counter()
         self.fd = os.open(self.path, os.O_RDWR | os.O_CREAT, 0o600)     # empty file = nothing claimed yet
         import fcntl
         fcntl.flock(self.fd, fcntl.LOCK_EX)
@@ -101,10 +103,12 @@ class WorkQueue:
                 os.ftruncate(self.fd, 0)          # left behind by a job whose rank 0 died before its unlink
         finally:
             fcntl.flock(self.fd, fcntl.LOCK_UN)
+        self.open_s = time.perf_counter() - t0
 
     def claim(self):
         """the next item indices of this rank ([] when the queue is drained)"""
         import fcntl
+        t0 = time.perf_counter()
         fcntl.flock(self.fd, fcntl.LOCK_EX)
         try:
             os.lseek(self.fd, 0, os.SEEK_SET)
@@ -116,6 +120,9 @@ class WorkQueue:
                 os.write(self.fd, b"%-31d" % hi)
         finally:
             fcntl.flock(self.fd, fcntl.LOCK_UN)
+        self.n_claims += 1
+        self.n_items += hi - lo
+        self.claim_s += time.perf_counter() - t0
         return self.order[lo:hi]
 
     def close(self, unlink=False):

@@ -461,3 +461,40 @@ def test_row_blocks_format_natively_like_the_row_path(tmp_path):
             back = cli.RowBlock.concat([cli.RowBlock.from_bytes(x.to_bytes()) for x in parts], coding).sorted()
             assert (back.meta == blk.meta).all() and (back.rec == blk.rec).all() and back.specials == blk.specials
             assert coding is False or (back.syn == blk.syn).all()
+
+
+def test_command_line_exits_like_python_when_it_dies_before_the_first_scan(tmp_path):
+    """The prewarm thread (pfa_prewarm, started by __main__ before the imports) is never left joinable in static storage:
+    an exception ahead of pfa_init() — closed stdin at the prompt (PolyFastA.py:84-88), an unlistable directory with
+    --pipe (:93-94) — ends in a traceback and exit code 1 as in the reference, not in std::terminate (134)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, "-m", "polyfasta_amd"], stdin=subprocess.DEVNULL, capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=120)
+    assert p.returncode == 1 and "EOFError" in p.stderr, (p.returncode, p.stderr[-500:])
+    p = subprocess.run([sys.executable, "-m", "polyfasta_amd", "--pipe", "-d", str(tmp_path / "nope")], stdin=subprocess.DEVNULL,
+                       capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=120)
+    assert p.returncode == 1 and "FileNotFoundError" in p.stderr, (p.returncode, p.stderr[-500:])
+    # the launcher of `--gpus N` does not prewarm (it must not touch the GPU before it starts its ranks)
+    code = (f"src = open({os.path.join(ROOT, 'polyfasta_amd', '__main__.py')!r}).read().split('_prewarmed = None')[0]\n"
+            "ns = {}; exec(src, ns)\n"
+            "f = ns['_launcher_only']\n"
+            "assert f(['-d', 'x', '--gpus', '4']) and f(['--gpus=2']) and not f(['--gpus', '1']) and not f(['-d', 'x']) and not f(['--gpus'])\n")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr[-800:]
+
+
+def test_ranks_get_the_ipc_mode_whoever_launched_them(monkeypatch):
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 is in the environment of every rank of a multi-GPU job before the HIP runtime comes up
+    (ranks started by torch.distributed.run do not pass through dist.spawn_ranks); a value the user exported is kept."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from polyfasta_amd import _lib\n"
+            "_lib.load()\n"
+            "print(os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', 'unset'))\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("HSA_ENABLE_IPC_MODE_LEGACY", "WORLD_SIZE")}
+    for extra, want in (({"WORLD_SIZE": "8"}, "0"), ({"WORLD_SIZE": "8", "HSA_ENABLE_IPC_MODE_LEGACY": "1"}, "1"), ({}, "unset")):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, **extra), timeout=120)
+        assert p.returncode == 0 and p.stdout.strip() == want, (extra, p.stdout, p.stderr[-500:])
