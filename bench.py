@@ -35,6 +35,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# aggregate read() rate of one host out of the page cache, all loader threads of all ranks together (profiles/r04_read_vs_mmap_8proc.txt:
+# 8 processes x 16 threads; r03_ingest_probe_host_ceiling.txt: one process): what bounds files -> CSV on 8 GPUs of one host
+HOST_READ_GBPS = 220.0
+DETAIL = {}             # the long form of every leg (prose, every counter): one `BENCH_DETAIL {...}` line on stderr
+
+
+def rnd(x, n=4):
+    """floats of the JSON line rounded to `n` significant digits (the line stays under 8 KB; full precision goes to stderr)"""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}")
+    if isinstance(x, dict):
+        return {k: rnd(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [rnd(v, n) for v in x]
+    return x
+
+
+def rows_equal(got, want, jc):
+    """two CSV rows field by field: equal text, or floats within 1e-9 relative (JC-corrected pi columns 1e-6; Tajima's D, a
+    cancelling difference, also within 1e-9 absolute)"""
+    fa, fb = got.split(","), want.split(",")
+    if len(fa) != len(fb):
+        return False
+    for x, y in zip(fa, fb):
+        if x == y:
+            continue
+        try:
+            fx, fy = float(x), float(y)
+        except ValueError:
+            return False
+        tol = 1e-6 if jc else 1e-9
+        if not (abs(fx - fy) <= tol * max(abs(fx), abs(fy)) or abs(fx - fy) <= 1e-9):
+            return False
+    return True
 
 
 def parse(argv=None):
@@ -133,6 +167,11 @@ class Workload:
         self.dev.free()
 
 
+WORKLOAD_KEYS = {"C4_coding_50x9000": "C4", "C3_pops_2x100x100000": "C3_split", "C3_pops_row_index_lists": "C3_rowidx",
+                 "N200_plain_200x100000": "N200", "N200_coding_200x9000": "N200_cds", "N1000_coding_1000x9000": "N1000_cds",
+                 "N5000_coding_5000x9000": "N5000_cds", "C5_batch_100000x50x10000": "C5_100k"}
+
+
 def extra_workloads(args):
     """The other BASELINE shapes as short device-resident passes (kernel time from HIP events)."""
     out = {}
@@ -155,9 +194,12 @@ def extra_workloads(args):
         except Exception as e:                  # noqa: BLE001  (e.g. not enough free HBM for the 50 GB batch)
             out[key] = {"error": f"{type(e).__name__}: {e}"}
             continue
-        out[key] = w.measure(steps=24 if kw["batch"] < 100000 else 10, warmup=6 if kw["batch"] < 100000 else 2)
+        full = w.measure(steps=24 if kw["batch"] < 100000 else 10, warmup=6 if kw["batch"] < 100000 else 2)
         o = w.plan.fetch()
-        out[key]["check"] = {"mean_seg_sites": float(o.results["seg_sites"].mean()), "sum_H": int(o.results["H"].sum())}
+        full["check"] = {"mean_seg_sites": float(o.results["seg_sites"].mean()), "sum_H": int(o.results["H"].sum())}
+        DETAIL.setdefault("workloads", {})[key] = full
+        out[key] = {"frac": full["frac"], "ms": full["kernel_ms_avg"], "p50": full["kernel_ms_p50"], "p95": full["kernel_ms_p95"],
+                    "GBps": full["achieved"], "kernel": full["kernel"].split(" units=")[0].replace("pfa::", ""), "sum_H": full["check"]["sum_H"]}
         w.close()
     return out
 
@@ -186,32 +228,60 @@ def small_launches(hw, args):
     for _ in range(60):
         one.run_fetch(hw.dev)
     k = one.kernel_ms(50)
-    rep["single_alignment"] = {"us_per_scan_and_fetch": per * 1e6, "us_per_scan_and_fetch_c_abi": per_abi * 1e6, "kernel_us": float(k.mean()) * 1e3, "kernel_us_min": float(k.min()) * 1e3,
-                               "plan": one.description,
-                               "note": "one N x L alignment per launch, bases resident, records fetched after every scan"}
+    # one N x L alignment per launch, bases resident, records fetched after every scan
+    rep["single_alignment"] = {"us_per_scan_and_fetch": per * 1e6, "us_per_scan_and_fetch_c_abi": per_abi * 1e6, "kernel_us": float(k.mean()) * 1e3, "kernel_us_min": float(k.min()) * 1e3}
+    DETAIL["single_alignment_plan"] = one.description
     one.close()
     c3 = Workload(rows=100, sites=100000, batch=1, pops=2, theta=args.theta, stride_align=args.stride_align)
     for _ in range(20):
         c3.plan.run_fetch(c3.dev)
     k = c3.plan.kernel_ms(16)
+    # BASELINE configs[2] literally: one 200 x 100 kb matrix, two 100-row populations, one launch
     rep["config3_one_launch"] = {"kernel_us": float(k.mean()) * 1e3, "kernel_us_min": float(k.min()) * 1e3,
-                                 "bytes": c3.alg_bytes, "achieved_GBps": c3.alg_bytes / (float(k.mean()) * 1e-3) / 1e9,
-                                 "plan": c3.plan.description,
-                                 "note": "BASELINE configs[2] literally: one 200 x 100 kb matrix, two 100-row populations, one launch"}
+                                 "bytes": c3.alg_bytes, "achieved_GBps": c3.alg_bytes / (float(k.mean()) * 1e-3) / 1e9}
+    DETAIL["config3_one_launch_plan"] = c3.plan.description
     c3.close()
     return rep
+
+
+def sample_indices(M, k=48):
+    """`k` file indices strided over the whole directory, first and last included"""
+    return sorted(set(int(x) for x in np.linspace(0, M - 1, min(k, M))))
+
+
+def check_rows(rows, mats, idx, M, L, flags, name_of, n_rows=50):
+    """The rows of the sampled files (every column) against the checker: integers and text equal, floats to 1e-9 (JC pi 1e-6);
+    row count and the name column of EVERY row.  `mats[j]` = matrix of file idx[j]."""
+    from oracle import c_oracle
+    from oracle import polyfasta_oracle as orc
+    cds, jc = "--cds" in flags, "--jc" in flags
+    keys = flags[flags.index("-p") + 1].split(",") if "-p" in flags else None
+    per = len(keys) if keys else 1
+    ok = len(rows) == M * per and [r.split(",", 1)[0] for r in rows[::per]] == [name_of(m) for m in range(M)]
+    if not ok:
+        return False
+    from polyfasta_amd import synth
+    hdr = synth.headers_for(n_rows, 2 if keys else 0)
+    for j, i in enumerate(idx):
+        for k in range(per):
+            sub = [r for r, h in enumerate(hdr) if keys[k] in h] if keys else None          # PolyFastA.py:125
+            o = c_oracle.scan(mats[j], rows=sub, cds=cds)
+            want = orc.row_from_counts(name_of(i), keys[k] if keys else "NA", len(sub) if keys else n_rows, L, o, cds, jc)
+            if not rows_equal(rows[i * per + k], want, jc):
+                return False
+    return True
 
 
 def end_to_end(args):
     """FASTA files in tmpfs -> CSV rows through the CLI (`python -m polyfasta_amd -d DIR -o out.csv -s [flags]`,
     in-process), per mode: plain on BASELINE configs[1] files (50 x 10 kb), `--cds --jc`, `--pops pop1,pop2` and
     `--pops pop1,pop2 --cds --jc` on in-frame 50 x 9 kb files with pop1_* / pop2_* headers.  Every mode: best and
-    median of the warm runs, a stage breakdown from the ingest's own counters, and its first rows against the C oracle."""
+    median of the warm runs, a stage breakdown from the ingest's own counters, and the rows of 48 files strided over the
+    whole directory (first and last included), every column, against the checker (C oracle integers + its own finishing math)."""
     import io
     import shutil
     import tempfile
     from contextlib import redirect_stdout
-    from oracle import c_oracle
     from polyfasta_amd import _lib, cli, scan, synth
     lib = _lib.load()
     N = 50
@@ -227,18 +297,20 @@ def end_to_end(args):
     M2 = M1
     root = tempfile.mkdtemp(prefix="pfa_e2e_", dir=root0)
     out = os.path.join(tempfile.gettempdir(), f"pfa_e2e_out_{os.getpid()}.csv")
-    report = {"scratch": root0, "command": "python -m polyfasta_amd -d DIR -o out.csv -s [mode flags] (in-process, page-cached files in tmpfs; warm = the "
-                         "pinned ring and the device buffers of the process exist, as for every batch after a job's first)",
-              "target_alignments_per_s": 10000, "pcie_h2d_peak_GBps_measured": 57.5}
+    # in-process, page-cached files in tmpfs; warm = the pinned ring and the device buffers of the process exist, as for every
+    # batch after a job's first
+    report = {"files": M1, "scratch": root0}
+    detail = DETAIL.setdefault("end_to_end", {"command": "python -m polyfasta_amd -d DIR -o out.csv -s [mode flags] (in-process)", "target_alignments_per_s": 10000,
+                                              "pcie_h2d_peak_GBps_measured": 57.5})
     try:
         def write_dir(name, M, L, coding, pops):
-            """M files of N x L in a fresh directory, generated 2 048 at a time; returns the directory and the first 48 matrices"""
+            """M files of N x L in a fresh directory, generated 2 048 at a time; returns the directory, the sampled file indices and their matrices"""
             d = os.path.join(root, name)
             os.makedirs(d)
             p = synth.make_params(N, args.theta)
             stride = scan.row_stride_for(L, 128)
             hdr = [f">{h}\n".encode() for h in synth.headers_for(N, pops)]
-            keep = None
+            idx, keep = sample_indices(M), {}
             for m0 in range(0, M, 2048):
                 mc = min(2048, M - m0)
                 sp = _lib.SynthParamsC(seed=7, first_aln=m0, n_aln=mc, n_rows=N, n_sites=L, row_stride=stride, seg_thresh=p.seg_thresh,
@@ -250,36 +322,18 @@ def end_to_end(args):
                     mat = bases[m * N * stride:(m + 1) * N * stride].reshape(N, stride)[:, :L]
                     with open(os.path.join(d, f"aln{m0 + m:06d}.fa"), "wb") as fh:
                         fh.write(b"".join(h + mat[i].tobytes() + b"\n" for i, h in enumerate(hdr)))
-                if keep is None:
-                    keep = bases.reshape(mc, N, stride)[:48, :, :L].copy()
-            return d, keep
+                    if m0 + m in idx:
+                        keep[m0 + m] = mat.copy()
+            return d, idx, [keep[i] for i in idx]
 
         t0 = time.perf_counter()
-        d1, b1 = write_dir("plain", M1, 10000, False, 0)
-        d2, b2 = write_dir("coding", M2, 9000, True, 2)
-        report["write_files_s"] = time.perf_counter() - t0
+        d1, i1, b1 = write_dir("plain", M1, 10000, False, 0)
+        d2, i2, b2 = write_dir("coding", M2, 9000, True, 2)
+        detail["write_files_s"] = time.perf_counter() - t0
 
-        def check(rows, bases, M, L, flags):
-            """the first 48 files' rows against the C oracle (integers exact, pi to 1e-9)"""
-            cds, pops = "--cds" in flags, "-p" in flags
-            per = 2 if pops else 1
-            ok = len(rows) == M * per and [r.split(",")[0] for r in rows[::per]] == [f"aln{m:06d}.fa" for m in range(M)]
-            for i in range(min(48, M)):
-                for k in range(per):
-                    f = rows[i * per + k].split(",")
-                    mat = np.ascontiguousarray(bases[i][k::2] if pops else bases[i])
-                    o = c_oracle.scan(mat, cds=cds)
-                    n = mat.shape[0]
-                    if not cds:
-                        pi = o["H"] / (n * (n - 1)) / L
-                        ok = ok and int(f[3]) == n and int(f[4]) == o["S"] and (o["S"] == 0 or abs(float(f[5]) - pi) <= 1e-9 * pi)
-                    else:
-                        ok = ok and int(f[4]) == n and (int(f[5]), int(f[6]), int(f[13])) == (o["seg_S"], o["seg_N"], o["nstops"])
-            return bool(ok)
-
-        modes = (("plain", d1, b1, M1, 10000, []), ("cds_jc", d2, b2, M2, 9000, ["--cds", "--jc"]),
-                 ("pops", d2, b2, M2, 9000, ["-p", "pop1,pop2"]), ("pops_cds_jc", d2, b2, M2, 9000, ["-p", "pop1,pop2", "--cds", "--jc"]))
-        for name, d, bases, M, L, flags in modes:
+        modes = (("plain", d1, i1, b1, M1, 10000, []), ("cds_jc", d2, i2, b2, M2, 9000, ["--cds", "--jc"]),
+                 ("pops", d2, i2, b2, M2, 9000, ["-p", "pop1,pop2"]), ("pops_cds_jc", d2, i2, b2, M2, 9000, ["-p", "pop1,pop2", "--cds", "--jc"]))
+        for name, d, idx, mats, M, L, flags in modes:
             times, stats = [], None
             for rep in range(1 + args.e2e_reps):
                 if os.path.exists(out):
@@ -297,20 +351,18 @@ def end_to_end(args):
             text_bytes = sum(os.path.getsize(os.path.join(d, f"aln{m:06d}.fa")) for m in (0, M - 1)) / 2 * M
             nt = max(stats["loader_threads"], 1)
             report[name] = {
-                "flags": " ".join(flags), "files": M, "rows": len(rows), "shape": f"{N} x {L}",
-                "alignments_per_s": M / best, "rows_per_s": len(rows) / best, "seconds": best, "text_GBps": text_bytes / best / 1e9,
-                "median_alignments_per_s": M / med, "first_run_s": times[0], "warm_runs": len(warm),
-                "rows_ok": rc == 0 and check(rows, bases, M, L, flags),
-                # where the best run's time went (stages overlap: loaders, link and card run concurrently)
-                "stages": {"startup_s (argparse, listdir, sorted, path table)": best - stats["wall_s"] + stats.get("open_s", 0.0),
-                           "read_s per loader thread": stats["read_thread_s"] / nt,
-                           "loader_threads": nt, "read_GBps_all_threads": stats["bytes_read"] / max(stats["read_thread_s"] / nt, 1e-9) / 1e9,
-                           "h2d_busy_s": stats["copy_busy_s"], "h2d_GBps_while_busy": stats["bytes_copied"] / max(stats["copy_busy_s"], 1e-9) / 1e9,
-                           "index+pack+copy_s per loader thread": stats["index_thread_s"] / nt, "turn / slot wait_s per loader thread": stats["turn_wait_thread_s"] / nt,
-                           "transport_bytes / text_bytes": stats["bytes_copied"] / max(stats["bytes_read"], 1), "wait_for_scan_s": stats["fetch_wait_s"],
-                           "rows+emit_s": stats["rows_s"] + stats["flush_s"], "batches": stats["batches"]}}
-        report.update({k: report["plain"][k] for k in ("alignments_per_s", "seconds", "files", "text_GBps", "rows_ok")})
-        report["loader_threads"] = report["plain"]["stages"]["loader_threads"]
+                "best": M / best, "median": M / med, "s": best, "first_s": times[0], "GBps": text_bytes / best / 1e9, "rows": len(rows),
+                "rows_ok": rc == 0 and check_rows(rows, mats, idx, M, L, flags, lambda m: f"aln{m:06d}.fa"),
+                # where the best run's time went (stages overlap: loaders, link and card run concurrently); seconds; per loader thread where it says _thr
+                "stages": {"startup": best - stats["wall_s"] + stats.get("open_s", 0.0), "read_thr": stats["read_thread_s"] / nt,
+                           "pack_thr": stats["index_thread_s"] / nt, "slot_wait_thr": stats["turn_wait_thread_s"] / nt, "h2d_busy": stats["copy_busy_s"],
+                           "scan_wait": stats["fetch_wait_s"], "next_wait": stats.get("next_wait_s", 0.0), "rows": stats["rows_s"] + stats["flush_s"],
+                           "close": stats.get("close_s", 0.0), "batches": stats["batches"]}}
+            detail[name] = {"flags": " ".join(flags), "files": M, "shape": f"{N} x {L}", "times_s": times, "stats_of_best_run": stats,
+                            "read_GBps_all_threads": stats["bytes_read"] / max(stats["read_thread_s"] / nt, 1e-9) / 1e9,
+                            "h2d_GBps_while_busy": stats["bytes_copied"] / max(stats["copy_busy_s"], 1e-9) / 1e9,
+                            "transport_bytes / text_bytes": stats["bytes_copied"] / max(stats["bytes_read"], 1), "checked_files": idx}
+            report["loader_threads"] = nt
         return report
     finally:
         shutil.rmtree(root, ignore_errors=True)
@@ -325,18 +377,31 @@ def e2e_ranks_paths():
     return root, os.path.join(tempfile.gettempdir(), f"pfa_e2e_ranks_out_{os.getppid()}.csv")
 
 
+RANK_STAGES = (  # (short key in the line, key in cli.last_stats, per loader thread?)
+    ("pre", "main_pre_s", 0), ("open", "open_s", 0), ("q_open", "queue_open_s", 0), ("claims", "claims", 0), ("claim", "claim_s", 0),
+    ("files", "claimed_files", 0), ("batches", "batches", 0), ("threads", "loader_threads", 0), ("read_thr", "read_thread_s", 1),
+    ("pack_thr", "index_thread_s", 1), ("slot_wait_thr", "turn_wait_thread_s", 1), ("h2d_busy", "copy_busy_s", 0),
+    ("next_wait", "next_wait_s", 0), ("scan_wait", "fetch_wait_s", 0), ("block", "rows_s", 0), ("format", "format_s", 0),
+    ("flags_gather", "flags_gather_s", 0), ("gather", "gather_s", 0), ("gather_B", "gather_bytes", 0), ("root_write", "root_merge_write_s", 0),
+    ("barrier", "barrier_s", 0), ("flush", "flush_s", 0), ("close", "close_s", 0), ("run_files", "wall_s", 0), ("main", "main_s", 0))
+
+ranks_progress = {"stage": "not started"}     # what the N > 1 leg was doing last (the watchdog's report)
+
+
 def end_to_end_ranks(args, comm, rank, world):
     """The thing north_star shards, measured: `--dir` through the shared work queue on `world` ranks.  Every rank
     writes its share of one tmpfs directory (N = 50 x 10 kb files, `--e2e-files-per-rank` per rank: weak scaling),
     then all ranks run `python -m polyfasta_amd -d DIR -o out.csv -s` in-process on this bench's communicator: each drains
-    dist.WorkQueue, the row blocks travel to rank 0 once, rank 0 orders and writes them.  The timed region is the whole
-    cli.main() of the slowest rank (the gather and rank 0's emit are inside); rows are checked against the C oracle."""
+    dist.WorkQueue, the rows travel to rank 0 once, rank 0 orders and writes them.  The timed region is the whole
+    cli.main() of the slowest rank (the gather and rank 0's emit are inside).  Reported with it: the stage table of the best
+    run, one column per rank (cli.last_stats: queue claims, loaders, link, waits, gather, rank 0's write, barrier, close), and
+    rank 0 alone on the same directory (`solo`: the single-process path on the same files, the other ranks waiting) — the
+    difference is what the multi-rank machinery costs when the ranks share one GPU, and what it should win when they do not.
+    Rows: 48 files strided over the whole directory, every column, against the checker; every row's name."""
     import io
     import shutil
-    import tempfile
     from contextlib import redirect_stdout
-    from oracle import c_oracle
-    from polyfasta_amd import _lib, cli, scan, synth
+    from polyfasta_amd import _lib, cli, dist, scan, synth
     lib = _lib.load()
     N, L = 50, 10000
     per = args.e2e_files_per_rank
@@ -344,7 +409,9 @@ def end_to_end_ranks(args, comm, rank, world):
     root, out = e2e_ranks_paths()
     p = synth.make_params(N, args.theta)
     stride = scan.row_stride_for(L, 128)
+    prog = ranks_progress
     try:
+        prog["stage"] = "writing the directory"
         if rank == 0:
             shutil.rmtree(root, ignore_errors=True)
             os.makedirs(root)
@@ -355,36 +422,75 @@ def end_to_end_ranks(args, comm, rank, world):
         _lib.check(lib.pfa_synth_fill_host(_lib.ptr(bases), ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(p.cdf)),
                                            _lib.ptr(np.ascontiguousarray(p.units))))
         hdr = [f">indiv{i + 1}\n".encode() for i in range(N)]
+        idx = sample_indices(M)
+        mine = {}
         for k in range(per):
             mat = bases[k * N * stride:(k + 1) * N * stride].reshape(N, stride)[:, :L]
             with open(os.path.join(root, f"aln{rank * per + k:07d}.fa"), "wb") as fh:
                 fh.write(b"".join(h + mat[i].tobytes() + b"\n" for i, h in enumerate(hdr)))
+            if rank * per + k in idx:
+                mine[rank * per + k] = mat.copy()
+        del bases
+        sampled = comm.gather_objects(mine, dst=0)           # the matrices of the sampled files, from the ranks that wrote them
         comm.barrier()
-        times = []
+        times, stats, own = [], [], []
         for rep in range(1 + args.e2e_reps):
+            prog["stage"] = f"run {rep} of {1 + args.e2e_reps}: before the start barrier"
             if rank == 0 and os.path.exists(out):
                 os.unlink(out)
             comm.barrier()
+            prog["stage"] = f"run {rep} of {1 + args.e2e_reps}: inside cli.main (shared queue, gather, rank 0's write)"
             t0 = time.perf_counter()
             with redirect_stdout(io.StringIO()):
                 rc = cli.main(["-d", root, "-o", out, "-s"], comm=comm, close_comm=False)
-            times.append(comm.max_float(time.perf_counter() - t0))
+            own.append(time.perf_counter() - t0)
+            prog["stage"] = f"run {rep} of {1 + args.e2e_reps}: waiting for the slowest rank"
+            times.append(comm.max_float(own[-1]))
+            stats.append(dict(cli.last_stats))
             comm.barrier()        # rank 0 has removed the queue file: the next run makes its own
+        best = 1 + int(np.argmin(times[1:]))                 # the same run on every rank (times are maxima over the ranks)
+        st = dict(stats[best], own_wall_s=own[best])
+        prog["stage"] = "gathering the stage tables"
+        table = comm.gather_objects(st, dst=0)
+        rows = open(out).read().splitlines() if rank == 0 else None
+        # rank 0 alone on the same directory (the single-process path of the same build on the same files); the others wait
+        solo = []
+        prog["stage"] = "rank 0 alone on the same directory"
+        if rank == 0:
+            for rep in range(1 + min(args.e2e_reps, 3)):
+                os.unlink(out)
+                t0 = time.perf_counter()
+                with redirect_stdout(io.StringIO()):
+                    rc1 = cli.main(["-d", root, "-o", out, "-s"], comm=dist.SoloComm(), close_comm=False)
+                solo.append(time.perf_counter() - t0)
+            rows_solo = open(out).read().splitlines()
+        comm.barrier()
         if rank != 0:
             return None
-        rows = open(out).read().splitlines()
-        ok = rc == 0 and len(rows) == M and [r.split(",")[0] for r in rows] == [f"aln{m:07d}.fa" for m in range(M)]
-        s_cpu, h_cpu = c_oracle.scan_many(bases, min(48, per), N, L, stride)      # rank 0 wrote files 0 .. per-1
-        for i in range(min(48, per)):
-            f = rows[i].split(",")
-            pi = int(h_cpu[i]) / (N * (N - 1)) / L
-            ok = ok and int(f[4]) == int(s_cpu[i]) and abs(float(f[5]) - pi) <= 1e-9 * pi
+        mats = {}
+        for part in sampled:
+            mats.update(part)
+        ok = rc == 0 and check_rows(rows, [mats[i] for i in idx], idx, M, L, [], lambda m: f"aln{m:07d}.fa")
         warm = sorted(times[1:])
-        return {"files": M, "files_per_rank": per, "ranks": world, "alignments_per_s": M / warm[0], "seconds": warm[0],
-                "median_alignments_per_s": M / warm[len(warm) // 2], "first_run_s": times[0], "text_GBps": M * N * (L + 10) / warm[0] / 1e9,
-                "rows_ok": bool(ok), "scaling": "weak",
-                "command": "python -m polyfasta_amd -d DIR -o out.csv -s on every rank (in-process, shared work queue, one gather to rank 0)"}
+        solo_warm = sorted(solo[1:])
+        stages = {}
+        for short, key, per_thread in RANK_STAGES:
+            col = [t.get(key, 0) / (max(t.get("loader_threads", 1), 1) if per_thread else 1) for t in table]
+            stages[short] = [int(v) if short in ("claims", "files", "batches", "threads", "gather_B") else float(f"{v:.4g}") for v in col]
+        stages["wall"] = [float(f"{t['own_wall_s']:.4g}") for t in table]
+        DETAIL["end_to_end_ranks"] = {"times_s_max_over_ranks": times, "per_rank_stats_of_best_run": table, "solo_times_s": solo,
+                                      "command": "python -m polyfasta_amd -d DIR -o out.csv -s on every rank (in-process, shared work queue, one gather to rank 0)"}
+        return {"files": M, "files_per_rank": per, "ranks": world, "best": M / warm[0], "median": M / warm[len(warm) // 2], "s": warm[0],
+                "first_s": times[0], "GBps": M * N * (L + 10) / warm[0] / 1e9, "rows_ok": bool(ok), "scaling": "weak",
+                "solo_rank0_same_files": {"best": M / solo_warm[0], "median": M / solo_warm[len(solo_warm) // 2], "s": solo_warm[0],
+                                          "rows_equal": rc1 == 0 and rows_solo == rows},
+                # seconds of the multi-rank run beyond rank 0 alone on the same files (ranks sharing ONE GPU: the machinery's cost;
+                # ranks on GPUs of their own: negative = the gain)
+                "s_beyond_solo": warm[0] - solo_warm[0],
+                "host_read_ceiling_alignments_per_s": HOST_READ_GBPS * 1e9 / (N * (L + 10)),
+                "stages_per_rank_of_best_run_s": stages}
     finally:
+        prog["stage"] += " (cleanup)"
         comm.barrier()
         if rank == 0:
             shutil.rmtree(root, ignore_errors=True)
@@ -402,8 +508,8 @@ def cold_start(args):
     import tempfile
     from polyfasta_amd import synth
     root = tempfile.mkdtemp(prefix="pfa_cold_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    rep = {"command": "python -m polyfasta_amd -f FILE [flags] in a fresh process (subprocess), page-cached file, stdout to a pipe",
-           "reference_whole_process_s": "0.15-0.17 (config 2, survey container, BASELINE.md §2)"}
+    # python -m polyfasta_amd -f FILE [flags] in a fresh process (subprocess), page-cached file, stdout to a pipe
+    rep = {"reference_whole_process_s": "0.15-0.17 (config 2, survey container)"}
     try:
         cases = (("config2_50x10000", 50, 10000, False, 0, []),
                  ("config3_200x100000_pops_jc", 200, 100000, False, 2, ["-p", "pop1,pop2", "--jc"]),
@@ -438,9 +544,11 @@ def cold_start(args):
                 continue
             order = np.argsort(walls[1:]) + 1            # the first run pages the libraries in: reported apart
             med = int(order[len(order) // 2])
-            rep[name] = {"wall_s_median_of_5": walls[med], "wall_s_min": float(min(walls[1:])), "wall_s_first_run": walls[0],
-                         "phases_s_of_the_median_run": phases[med] if len(phases) == len(walls) else None,
-                         "rows": len(rows) - 1, "flags": " ".join(flags)}
+            ph = phases[med] if len(phases) == len(walls) else None
+            rep[name] = {"median_s": walls[med], "min_s": float(min(walls[1:])), "first_s": walls[0], "rows": len(rows) - 1,
+                         # phases of the median run: interpreter + prewarm start, imports, argparse, dlopen, pfa_init (= the wait for hipInit), files -> rows, exit
+                         "phases_s": None if ph is None else [float(f"{v:.3g}") for v in ph.values()]}
+            DETAIL.setdefault("cold_start", {})[name] = {"walls_s": walls, "phases_s_of_the_median_run": ph, "flags": " ".join(flags)}
         return rep
     finally:
         shutil.rmtree(root, ignore_errors=True)
@@ -493,16 +601,12 @@ def cpu_baseline(args, hw):
         dt_py = time.perf_counter() - tp
         if dt_py >= min(args.cpu_seconds, 5.0):
             break
+    DETAIL["cpu_baseline"] = {"all_cores": f"the same scalar C scan on {T} host threads (every CPU this process may use) for {dt_mt:.1f} s",
+                              "pure_python": f"oracle/polyfasta_oracle.py (the reference's loop structure: getvarsites + polymorphism) on {n_py} alignment(s) "
+                                             f"of the same workload for {dt_py:.1f} s; S = {poly[0]} = the GPU's: {poly[0] == int(s[0])}"}
     return {"value": done / dt, "unit": "alignments/s", "cores": 1, "kind": "port",
-            "sample": f"{n_mat} distinct synthetic alignments ({N}x{L}, same generator) scanned repeatedly by "
-                      f"oracle/pfa_oracle.c for {dt:.1f} s on 1 of {os.cpu_count()} host cores",
-            "host_cores": os.cpu_count(),
-            "all_cores": {"value": done_mt / dt_mt, "unit": "alignments/s", "cores": T, "kind": "port",
-                          "sample": f"the same scalar C scan on {T} host threads (every core this process may use) for {dt_mt:.1f} s"},
-            "pure_python": {"value": n_py / dt_py, "unit": "alignments/s", "cores": 1, "kind": "port",
-                            "sample": f"oracle/polyfasta_oracle.py (the reference's loop structure: getvarsites + polymorphism) on "
-                                      f"{n_py} alignment(s) of the same workload for {dt_py:.1f} s; S = {poly[0]} = the GPU's: "
-                                      f"{poly[0] == int(s[0])}"}}, (s, h)
+            "sample": f"{n_mat} synthetic {N}x{L} alignments, oracle/pfa_oracle.c, {dt:.1f} s, 1 of {os.cpu_count()} host cores",
+            "all_cores": {"value": done_mt / dt_mt, "cores": T}, "pure_python": {"value": n_py / dt_py, "cores": 1}}, (s, h)
 
 
 def measured_traffic(cfg):
@@ -609,56 +713,65 @@ def main():
         N, L, B, K = hw.N, hw.L, hw.B, hw.K
         total_aln = world * B * K * args.steps   # scan units (alignment x population) = CSV rows
         default_shape = (N, L, args.coding, args.pops) == (50, 10000, False, 0)
+        traffic, traffic_source = measured_traffic({"rows": N, "sites": L, "batch_per_gpu": B, "row_stride": hw.stride, "workload": hw.label()})
         line = {
             "metric": "alignments/sec", "value": total_aln / dt, "unit": "alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "site_columns_per_sec": total_aln * L / dt,
-            "config": {"workload": ("BASELINE configs[1] shape as a device-resident batch: " if default_shape else "device-resident batch: ")
-                                   + hw.label() + f" per GPU per step, theta={args.theta}",
-                       "rows": N, "sites": L, "batch_per_gpu": B, "row_stride": hw.stride,
-                       "parallelism": f"independent alignments sharded over {world} rank(s), one process per GPU; one RCCL "
-                                      f"all-gather of the result records ({type(comm).__name__})" if world > 1 else "single GPU",
-                       "kernel_variant": {0: "lds_dma_nt", 2: "lds_dma_default_policy"}[args.variant],
-                       "tiles_per_chunk": plan.tiles_per_chunk, "lds_bytes_per_wave": plan.lds_bytes,
-                       "rows_per_chunk": plan.rows_per_chunk, "tile_width": plan.tile_width},
+            "config": {"workload": ("BASELINE configs[1] shape, device-resident: " if default_shape else "device-resident: ") + hw.label() + " per GPU per step",
+                       "rows": N, "sites": L, "batch_per_gpu": B, "row_stride": hw.stride, "theta": args.theta,
+                       "parallelism": f"{world} ranks, one per GPU, independent alignments, one gather of the records ({type(comm).__name__})" if world > 1 else "single GPU",
+                       "tile_width": plan.tile_width, "lds_bytes_per_wave": plan.lds_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": plan.description, "kernel_ms_avg": k_avg_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": plan.description.split(" units=")[0].replace("pfa::", ""), "kernel_ms_avg": k_avg_ms,
                          "algorithmic_bytes_per_launch": hw.alg_bytes,
-                         "frac_of_measured_copy_6290": achieved / 6290.0,
-                         # best plain streaming read measured on this pool (tools/ubench/read_stream.hip)
+                         # best plain streaming read measured on this pool (tools/ubench/read_stream.hip): 6 860 GB/s
                          "frac_of_measured_read_6860": achieved / 6860.0},
             "timing_ms": {"enqueue": t_enq * 1e3, "until_kernels_done": t_run * 1e3, "fetch": t_fetch * 1e3,
-                          "kernel_ms_min": float(kms.min()), "kernel_ms_max": float(kms.max()),
-                          "kernel_ms_p50": float(np.percentile(kms, 50)), "kernel_ms_p95": float(np.percentile(kms, 95)),
+                          "kernel_min": float(kms.min()), "kernel_max": float(kms.max()),
+                          "kernel_p50": float(np.percentile(kms, 50)), "kernel_p95": float(np.percentile(kms, 95)),
                           "kernel_runs_timed": int(len(kms))},
             "check": {"mean_seg_sites": float(res["seg_sites"].mean()),
                       "sum_H": int(res["H"].sum()),
                       "gathered_records": None if gathered is None else int(gathered.size),
                       "gathered_rank0_equals_fetch": None if gathered is None else bool((gathered[0] == res).all())},
         }
-        line["roofline"]["traffic"], line["roofline"]["traffic_source"] = measured_traffic(line["config"])
+        DETAIL["headline"] = {"kernel": plan.description, "traffic_source": traffic_source, "kernel_variant": {0: "lds_dma_nt", 2: "lds_dma_default_policy"}[args.variant],
+                              "tiles_per_chunk": plan.tiles_per_chunk, "rows_per_chunk": plan.rows_per_chunk, "frac_of_measured_copy_6290": achieved / 6290.0}
         if os.environ.get("PFA_ALLOW_SHARED_GPU") or os.environ.get("PFA_COMM_FACTORY"):
             # rehearsal switches (tests): ranks may share one device and talk through an injected communicator —
             # such a line is not a multi-GPU measurement, and says so
             line["rehearsal"] = {"shared_gpu": bool(os.environ.get("PFA_ALLOW_SHARED_GPU")), "comm": type(comm).__name__,
                                  "note": "n_gpus counts ranks, not devices: not a scaling measurement"}
+
+    def emit_line():
+        print(json.dumps(rnd(line, 6)), flush=True)
+        print("BENCH_DETAIL " + json.dumps(DETAIL, default=str), file=sys.stderr, flush=True)
+
     if world > 1 and comm is not None and not args.no_extras and "end_to_end" in args.legs.split(","):
         # The N > 1 end-to-end leg is a collective affair (shared queue, barriers, one gather): if a rank failed inside it the
         # others would wait for ever and the headline measured above would never be printed.  A watchdog per rank prints the
-        # line without the leg and ends the process cleanly when the leg has not come back in time.
+        # line without the leg — rank 0 — and ends the process with a NON-ZERO code (124, as timeout(1) does) when the leg has
+        # not come back in time: a hung multi-rank job never reads as a clean run, and every rank says on stderr what it was
+        # doing when the time ran out.
         import threading
 
         def bail():
+            print(f"bench.py: rank {rank} of {world}: the N > 1 end-to-end leg did not finish within {args.e2e_ranks_timeout} s; "
+                  f"last stage: {ranks_progress['stage']}", file=sys.stderr, flush=True)
             if rank == 0:
                 import shutil
                 time.sleep(0.5)                                              # the other ranks' watchdogs fire with this one: let them stop writing
                 shutil.rmtree(e2e_ranks_paths()[0], ignore_errors=True)      # gigabytes of tmpfs: not left behind
-                line["end_to_end"] = {"error": f"the N > 1 end-to-end leg did not finish within {args.e2e_ranks_timeout} s"}
-                print(json.dumps(line), flush=True)
-            os._exit(0)
+                line["end_to_end"] = {"error": f"the N > 1 end-to-end leg did not finish within {args.e2e_ranks_timeout} s", "rank": 0,
+                                      "stage": ranks_progress["stage"]}
+                emit_line()
+            else:
+                time.sleep(2.0)          # a launcher ends the job at the first non-zero exit: rank 0 prints the line first
+            os._exit(124)
         dog = threading.Timer(args.e2e_ranks_timeout, bail)
         dog.daemon = True
         dog.start()
@@ -666,12 +779,13 @@ def main():
             e2e_ranks = end_to_end_ranks(args, comm, rank, world)
         except Exception as e:              # noqa: BLE001   (the other ranks may be waiting at a barrier: let the watchdog end the job)
             e2e_ranks = {"error": f"{type(e).__name__}: {e}"}
-            if rank == 0:
-                line["end_to_end"] = e2e_ranks
+            ranks_progress["stage"] += f" -> {type(e).__name__}: {e}"
             dog.join()
         dog.cancel()
         if rank == 0:
             line["end_to_end"] = e2e_ranks
+            if "error" not in e2e_ranks:
+                line["roofline"]["end_to_end"] = {f"ranks{world}": [e2e_ranks["best"], e2e_ranks["median"]], "solo": [e2e_ranks["solo_rank0_same_files"]["best"], e2e_ranks["solo_rank0_same_files"]["median"]]}
     if rank == 0:
         extras = world == 1 and comm is None and not args.no_extras and default_shape
         if extras and not args.no_cpu_baseline:
@@ -696,14 +810,20 @@ def main():
                 line.update(sl if "error" not in sl else {"single_alignment": sl})
             hw.close()
             if "workloads" in legs:
-                line["workloads"] = leg(extra_workloads, args)
+                wl = leg(extra_workloads, args)
+                line["workloads"] = wl
+                # every workload's fraction of the 8 TB/s peak, where the driver's record keeps it
+                line["roofline"]["by_workload"] = {WORKLOAD_KEYS.get(k, k): v.get("frac") for k, v in wl.items() if isinstance(v, dict)}
             if "end_to_end" in legs:
-                line["end_to_end"] = leg(end_to_end, args)
+                e2e = leg(end_to_end, args)
+                line["end_to_end"] = e2e
+                # files -> CSV, alignments/s [best, median] per mode
+                line["roofline"]["end_to_end"] = {k: [v["best"], v["median"]] for k, v in e2e.items() if isinstance(v, dict) and "best" in v}
             if "cold_start" in legs:
                 line["cold_start"] = leg(cold_start, args)
         else:
             hw.close()
-        print(json.dumps(line), flush=True)
+        emit_line()
     else:
         hw.close()
     if comm is not None:

@@ -337,6 +337,48 @@ def result_row(d, seqlen, cds, name, pop, jc):
     return f"{name},{seqlen},{pop},{len(var[0])},{p[0]},{p[1]},{p[2]},{p[3]}"
 
 
+def polymorphism_from_counts(s, h, n, seqlen, jc):
+    """ref:502-520 from the integers a scan yields instead of the column lists: `s` variable columns among `n`
+    sequences and h = sum over them of (n^2 - sum_j c_j^2), so that ref:485-492's n/(n-1) * sum(1 - sum (c/n)^2)
+    is h / (n (n-1)).  The checker's own finishing math for directory-scale tests, where the column-by-column
+    functions above would take hours; pinned against them (tests/test_oracle_golden.py)."""
+    if s == 0:
+        return 0, 0, 0, "NA"
+    pi_total = h / (n * (n - 1))
+    a1 = sum(1 / i for i in range(1, n))
+    theta_total = s / a1
+    column = [0] * n
+    try:
+        tajima = (pi_total - theta_total) / Dvar([column] * s)
+    except ZeroDivisionError:
+        tajima = "NA"
+    pi_site = pi_total / seqlen
+    if jc:
+        try:
+            pi_site = jukes_cantor_correction(pi_total / seqlen)
+        except Exception:
+            pi_site = pi_total / seqlen
+    return s, pi_site, theta_total / seqlen, tajima
+
+
+def row_from_counts(name, pop, n, seqlen, o, cds, jc):
+    """One CSV row (ref:148-198) from the integer summary `o` of a unit (oracle/c_oracle.py: scan): keys S, H and, for
+    coding units, seg_S, seg_N, H_S, H_N, nstops, missing_cols, count_syn."""
+    if cds:
+        ssites = o["count_syn"]
+        nsites = (seqlen - 3 * o["missing_cols"]) - ssites
+        if o["S"] == 0:
+            return f"{name},{round(ssites, 2)},{round(nsites, 2)},{pop},{n},{NO_VAR},{NO_VAR},{0}"
+        ps = polymorphism_from_counts(o["seg_S"], o["H_S"], n, ssites, jc)
+        pn = polymorphism_from_counts(o["seg_N"], o["H_N"], n, nsites, jc)
+        return (f"{name},{round(ssites, 2)},{round(nsites, 2)},{pop},{n},"
+                f"{ps[0]},{pn[0]},{ps[1]},{pn[1]},{ps[2]},{pn[2]},{ps[3]},{pn[3]},{o['nstops']}")
+    if o["S"] == 0:
+        return f"{name},{seqlen},{pop},{n},{NO_VAR}"
+    p = polymorphism_from_counts(o["S"], o["H"], n, seqlen, jc)
+    return f"{name},{seqlen},{pop},{n},{p[0]},{p[1]},{p[2]},{p[3]}"
+
+
 def split_pop(d, key):
     """Intended behaviour of ref:125-133 (the reference crashes on Python 3 at
     ref:126): rows whose header contains `key` as a substring, file order."""

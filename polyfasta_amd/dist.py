@@ -410,6 +410,20 @@ class Comm:
         return [pickle.loads(b) for b in blobs] if self.rank == dst else None
 
 
+class SoloComm(Comm):
+    """A world of one: lets one rank of a job run the single-process path in-process (bench.py measures rank 0 alone on the
+    files the ranks have just shared out)."""
+
+    def barrier(self):
+        pass
+
+    def max_float(self, x: float) -> float:
+        return float(x)
+
+    def all_gather_fixed(self, buf: np.ndarray) -> np.ndarray:
+        return np.ascontiguousarray(buf, dtype=np.uint8).reshape(1, -1)
+
+
 class RcclComm(Comm):
     """RCCL through the C ABI (pfa_comm_* in include/pfa.h).  The process is bound to GPU
     LOCAL_RANK first (`_lib.init`): one rule for the scan and the communicator."""

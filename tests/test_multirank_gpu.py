@@ -179,23 +179,35 @@ def test_bench_with_two_ranks_on_one_gpu(gpu):
     assert j["value"] > 0 and "cpu_baseline" not in j and "workloads" not in j
     # the N > 1 end-to-end leg: both ranks drain the shared queue of one directory, rows gathered to rank 0 and oracle-checked
     e = j["end_to_end"]
-    assert e["ranks"] == 2 and e["files"] == 192 and e["rows_ok"] is True and e["alignments_per_s"] > 0, e
+    assert e["ranks"] == 2 and e["files"] == 192 and e["rows_ok"] is True and e["best"] > 0, e
     assert j["rehearsal"]["shared_gpu"] is True
+    # the stage table of the best run: one column per rank, every stage of the multi-rank path
+    st = e["stages_per_rank_of_best_run_s"]
+    for key in ("pre", "open", "q_open", "claims", "claim", "files", "batches", "threads", "read_thr", "pack_thr", "slot_wait_thr", "h2d_busy",
+                "next_wait", "scan_wait", "block", "format", "flags_gather", "gather", "gather_B", "root_write", "barrier", "flush", "close",
+                "run_files", "main", "wall"):
+        assert key in st and len(st[key]) == 2, key
+    assert sum(st["files"]) == 192 and min(st["claims"]) >= 1 and max(st["wall"]) <= e["s"] * 1.001 + 1e-6
+    # rank 0 alone on the same files (the single-process path), same rows
+    assert e["solo_rank0_same_files"]["rows_equal"] is True and e["solo_rank0_same_files"]["best"] > 0
+    assert e["host_read_ceiling_alignments_per_s"] > 1e5 and set(j["roofline"]["end_to_end"]) == {"ranks2", "solo"}
+    assert len(lines[0]) < 8192
 
 
 def test_bench_prints_its_line_when_the_multi_rank_end_to_end_leg_hangs(gpu):
     """The N > 1 end-to-end leg runs under a watchdog: when it does not come back (here: a 50 ms allowance), rank 0
-    still prints the ONE JSON line with the headline it measured before, the leg reported as an error, every rank
-    exits 0."""
+    still prints the ONE JSON line with the headline it measured before, the leg reported as an error with the stage that
+    was outstanding, and every rank exits NON-ZERO (124): a hung multi-rank job never reads as a clean run."""
     import json
     env = dict(os.environ, PFA_ALLOW_SHARED_GPU="1", PFA_COMM_FACTORY="tests._gloo_comm:GlooComm", PYTHONPATH=ROOT)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "512",
                         "--e2e-files-per-rank", "512", "--e2e-reps", "2", "--e2e-ranks-timeout", "0.05"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 124, (p.returncode, p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["value"] > 0 and "did not finish" in j["end_to_end"]["error"]
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "did not finish" in j["end_to_end"]["error"] and j["end_to_end"]["stage"]
+    assert "rank 1 of 2" in p.stderr and "last stage:" in p.stderr
     import glob
     assert not glob.glob("/dev/shm/pfa_e2e_ranks_*"), "the leg's tmpfs directory was left behind"

@@ -167,3 +167,41 @@ def test_unicode_sequences_g9(tmp_path):
             continue
         k, cds = key.split("|cds=")
         C.rows_close(orc.result_row(orc.split_pop(d, k), 60, bool(int(cds)), "accents.fa", k, False), row, rel=1e-12)
+
+
+def test_rows_from_integer_summaries_equal_the_reference_rows():
+    """orc.row_from_counts (the checker's finishing math on the C oracle's integers, what directory-scale GPU tests and the
+    bench's row checks use) prints the reference's rows: G1 and G5 coding rows, G8 (BASELINE configs 2-4), G6 populations."""
+    for fn, rec in C.load("g1_examples.json").items():
+        m = C.matrix_from_literal(orc.readfasta(f"{C.GOLDEN}/example_theta_0.01/{fn}"))
+        o = c_oracle.scan(m, cds=True)
+        for jc, key in ((False, "row"), (True, "row_jc")):
+            C.rows_close(orc.row_from_counts("x.fa", "NA", rec["N"], rec["L"], o, True, jc), rec["cds"][key], rel=1e-10, rel_jc=1e-10)
+        for jc, key in ((False, "poly"), (True, "poly_jc")):
+            got = orc.polymorphism_from_counts(o["S"], o["H"], rec["N"], rec["L"], jc)
+            assert got[0] == rec[key][0] and all(C.close(x, y, REL) for x, y in zip(got[1:], rec[key][1:]))
+    for rec in C.load("g5_cds.json"):
+        m = C.matrix_from_gen(rec["gen"]) if "gen" in rec else C.matrix_from_literal(rec["literal"])
+        o = c_oracle.scan(m, cds=True)
+        for jc, key in ((False, "row"), (True, "row_jc")):
+            C.rows_close(orc.row_from_counts("x.fa", "NA", m.shape[0], rec["L"], o, True, jc), rec["cds"][key], rel=1e-10, rel_jc=1e-10)
+    for case in C.load("g8_baseline_configs.json"):
+        g = case["gen"]
+        d, m = C.dict_from_gen(g), C.matrix_from_gen(g)
+        for key, want in case["rows"].items():
+            pop, jc = key.split("|")[0], key.endswith("jc=1")
+            rows = None if case["pops"] is None else [i for i, h in enumerate(d) if pop in h]
+            o = c_oracle.scan(m, rows=rows, cds=case["cds"])
+            n = m.shape[0] if rows is None else len(rows)
+            C.rows_close(orc.row_from_counts("x.fa", pop, n, g["L"], o, case["cds"], jc), want, rel=REL, rel_jc=REL, jc=jc)
+    for case in C.load("g6_pops.json"):
+        if case["extra_gen"]:
+            continue
+        d, m = C.dict_from_gen(case["gen"]), C.matrix_from_gen(case["gen"])
+        for key, want in case["rows"].items():
+            if want is None:
+                continue
+            pop, cds, jc = key.split("|")
+            rows = [i for i, h in enumerate(d) if pop in h]
+            o = c_oracle.scan(m, rows=rows, cds=cds == "cds=1")
+            C.rows_close(orc.row_from_counts("x.fa", pop, len(rows), case["gen"]["L"], o, cds == "cds=1", jc == "jc=1"), want, rel=1e-10, rel_jc=1e-10)
