@@ -422,6 +422,12 @@ int pfa_ingest_open(const char* const* paths, uint32_t n_files, const pfa_ingest
  * PFA_ERR_UNSUPPORTED when a name is not UTF-8 (the caller lists and sorts itself), PFA_ERR_IO when the
  * directory cannot be opened. */
 int pfa_ingest_open_dir(const char* dir, const pfa_ingest_opts* opts, pfa_ingest** out, uint32_t* n_files);
+/* The same job from a listing somebody else made (PolyFastA.py:93-94, :104): file f is "dir/" + names_blob[names_off[f] ..
+ * names_off[f+1]), in the order given (pfa_ingest_names() of the ingest that listed `dir`).  The ranks of a multi-GPU job
+ * take rank 0's listing this way: R processes walking one directory of 100 k entries at once serialise on its lock
+ * (26 ms for 4 ranks, 51 ms for 6 on a 16 384-file tmpfs directory; 5 ms alone). */
+int pfa_ingest_open_names(const char* dir, const char* names_blob, const uint64_t* names_off, uint32_t n_files,
+                          const pfa_ingest_opts* opts, pfa_ingest** out);
 /* path i of the ingest (owned by it) */
 const char* pfa_ingest_path(const pfa_ingest* ing, uint32_t i);
 /* append files (indices into `paths`; NULL = 0..n-1) to the feed order; `last` != 0: no
@@ -459,6 +465,15 @@ int64_t pfa_format_rows_indexed(const char* names_blob, const uint64_t* names_of
  * from it runs at the PCIe rate */
 int pfa_host_alloc(size_t bytes, void** out);
 int pfa_host_free(void* p);
+
+/* CPUs this process may keep busy — what the ingest sizes its loader pool by and what decides whether host waits
+ * spin or sleep: the CPUs it may run on and the CPU-time quota of its control group (cgroup v2 cpu.max / v1
+ * cpu.cfs_quota_us, the tightest from its group up to the root), shared out over the LOCAL_WORLD_SIZE ranks of the
+ * node; PFA_CPUS overrides.  No reference counterpart (PolyFastA.py:104 is one thread); it is here because one rank
+ * per GPU inside a container's CPU quota is how `--dir` runs on a shared node.
+ * With both arguments NULL: that number.  With a cgroup mount point and a /proc/<pid>/cgroup-style file: the quota
+ * found there alone, in CPUs (1e9 = none) — for tests. */
+double pfa_host_cpu_share(const char* cgroup_root, const char* proc_cgroup);
 
 #ifdef __cplusplus
 }

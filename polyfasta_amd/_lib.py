@@ -148,6 +148,7 @@ _PROTOTYPES = {
     "pfa_fasta_pack2": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp]),
     "pfa_ingest_open": (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.c_uint32, ctypes.POINTER(IngestOptsC), ctypes.POINTER(_vp)]),
     "pfa_ingest_open_dir": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(IngestOptsC), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_uint32)]),
+    "pfa_ingest_open_names": (ctypes.c_int, [ctypes.c_char_p, _vp, _vp, ctypes.c_uint32, ctypes.POINTER(IngestOptsC), ctypes.POINTER(_vp)]),
     "pfa_ingest_path": (ctypes.c_char_p, [_vp, ctypes.c_uint32]),
     "pfa_ingest_feed": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, ctypes.c_int]),
     "pfa_ingest_backlog": (ctypes.c_uint32, [_vp]),
@@ -159,6 +160,7 @@ _PROTOTYPES = {
                                                  ctypes.c_int, ctypes.c_int, _vp, ctypes.c_uint64, _vp]),
     "pfa_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "pfa_host_free": (ctypes.c_int, [_vp]),
+    "pfa_host_cpu_share": (ctypes.c_double, [ctypes.c_char_p, ctypes.c_char_p]),
     "pfa_comm_unique_id": (ctypes.c_int, [_vp]),
     "pfa_comm_init": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp]),
     "pfa_comm_rank": (ctypes.c_int, []),

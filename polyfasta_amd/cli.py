@@ -656,7 +656,8 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
     t00 = time.perf_counter()
     ing = None
     if paths is None:
-        ing = ingest.Ingest.from_dir(directory, keys=keys, cds=args.cds)
+        ing = (ingest.Ingest.from_dir_shared(directory, comm, keys=keys, cds=args.cds) if world > 1 and comm is not None
+               else ingest.Ingest.from_dir(directory, keys=keys, cds=args.cds))
         if ing is None:                      # a name that is not UTF-8, or a directory that cannot be listed: the reference's own way
             paths = sorted(directory + "/" + i for i in os.listdir(directory))
         else:

@@ -19,6 +19,8 @@ struct Context {
   int n_cu = 0;
   size_t lds_per_block = 0;
   hipStream_t stream = nullptr;
+  double cpu_share = 1e9;    // CPUs this process may keep busy (pfa_host.h: cpu_share)
+  bool spin_waits = true;    // host waits spin (enough CPUs) or sleep
 };
 
 Context& ctx();

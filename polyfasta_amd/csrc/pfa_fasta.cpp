@@ -14,7 +14,9 @@
 // PFA_FILE_UNSUPPORTED): the reference would decode them as UTF-8 and apply
 // Unicode case rules, outside this path's one-byte-per-base contract.
 // No exception and no abort crosses the ABI: every entry point catches.
+#include <sched.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <stdio.h>
@@ -254,7 +256,87 @@ bool pack2_row(const uint8_t* src, uint64_t n, uint8_t* dst) {
 
 }  // namespace pfa
 
+namespace pfa {
+
+static double read_quota_v2(const std::string& file) {
+  FILE* f = fopen(file.c_str(), "r");
+  if (!f) return 1e9;
+  char a[64] = "", b[64] = "";
+  const int n = fscanf(f, "%63s %63s", a, b);
+  fclose(f);
+  if (n < 2 || strcmp(a, "max") == 0) return 1e9;
+  const double q = atof(a), p = atof(b);
+  return q > 0 && p > 0 ? q / p : 1e9;
+}
+
+static double read_number(const std::string& file) {
+  FILE* f = fopen(file.c_str(), "r");
+  if (!f) return -1;
+  double v = -1;
+  if (fscanf(f, "%lf", &v) != 1) v = -1;
+  fclose(f);
+  return v;
+}
+
+double cgroup_cpu_quota(const char* cgroup_root, const char* proc_cgroup) {
+  double best = 1e9;
+  std::string v2_path = "/", v1_path = "/";
+  if (FILE* f = fopen(proc_cgroup, "r")) {
+    char line[4096];
+    while (fgets(line, sizeof(line), f)) {
+      // "0::/path" (v2) or "4:cpu,cpuacct:/path" (v1)
+      char* c1 = strchr(line, ':');
+      char* c2 = c1 ? strchr(c1 + 1, ':') : nullptr;
+      if (!c2) continue;
+      std::string ctl(c1 + 1, c2), path(c2 + 1);
+      while (!path.empty() && (path.back() == '\n' || path.back() == '\r')) path.pop_back();
+      if (ctl.empty()) v2_path = path;
+      else if ((',' + ctl + ',').find(",cpu,") != std::string::npos) v1_path = path;
+    }
+    fclose(f);
+  }
+  const std::string root(cgroup_root);
+  // v2: the group and every ancestor (a limit anywhere on the way up holds)
+  for (std::string p = v2_path;;) {
+    best = std::min(best, read_quota_v2(root + (p == "/" ? "" : p) + "/cpu.max"));
+    if (p == "/" || p.empty()) break;
+    const size_t sl = p.rfind('/');
+    p = sl == 0 || sl == std::string::npos ? "/" : p.substr(0, sl);
+  }
+  // v1: cpu controller mounted at <root>/cpu (or cpu,cpuacct)
+  for (const char* mnt : {"/cpu", "/cpu,cpuacct"}) {
+    for (std::string p = v1_path;;) {
+      const std::string dir = root + mnt + (p == "/" ? "" : p);
+      const double q = read_number(dir + "/cpu.cfs_quota_us"), per = read_number(dir + "/cpu.cfs_period_us");
+      if (q > 0 && per > 0) best = std::min(best, q / per);
+      if (p == "/" || p.empty()) break;
+      const size_t sl = p.rfind('/');
+      p = sl == 0 || sl == std::string::npos ? "/" : p.substr(0, sl);
+    }
+  }
+  return best;
+}
+
+double cpu_share() {
+  if (const char* e = getenv("PFA_CPUS")) { const double v = atof(e); if (v > 0) return v; }
+  cpu_set_t set;
+  double cpus = 1;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = (double)std::max(1, CPU_COUNT(&set));
+  double ranks = 1;
+  for (const char* var : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
+    if (const char* e = getenv(var)) { const long v = strtol(e, nullptr, 10); if (v > 0) { ranks = (double)v; break; } }
+  const double by_affinity = getenv("PFA_CPUS_ARE_MINE") ? cpus : cpus / ranks;
+  return std::max(1.0, std::min(by_affinity, cgroup_cpu_quota() / ranks));
+}
+
+}  // namespace pfa
+
 extern "C" {
+
+double pfa_host_cpu_share(const char* cgroup_root, const char* proc_cgroup) {
+  if (!cgroup_root && !proc_cgroup) return pfa::cpu_share();
+  return pfa::cgroup_cpu_quota(cgroup_root ? cgroup_root : "/sys/fs/cgroup", proc_cgroup ? proc_cgroup : "/proc/self/cgroup");
+}
 
 static int64_t fasta_index_impl(const uint8_t* text, uint64_t n_text, pfa_fasta_rec* recs, uint64_t cap) {
   if (!text && n_text) { pfa::set_error("pfa_fasta_index: text is NULL"); return PFA_ERR_ARG; }

@@ -39,4 +39,14 @@ int64_t index_compact(uint8_t* text, uint64_t n_text, std::vector<pfa_fasta_row>
 // undefined) when a byte is not A/C/G/T/a/c/g/t
 bool pack2_row(const uint8_t* src, uint64_t n, uint8_t* dst);
 
+// CPUs this PROCESS may keep busy: the CPUs it may run on (sched_getaffinity) and the CPU-time quota of its control
+// group (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us`: the tightest limit from the process's group up to the root), both
+// shared out over the `LOCAL_WORLD_SIZE` ranks of the node (the affinity share not when the rank has already bound itself to
+// its own CPUs, PFA_CPUS_ARE_MINE).  A container that may run on 256 CPUs but has a quota of 16 CPU-seconds per second is
+// frozen for the rest of every 100 ms period in which its threads used the quota up: loader pools and spinning waits
+// are sized by this number, not by the CPU count.  PFA_CPUS=x overrides it.
+double cpu_share();
+// the quota alone, for the whole control group (CPUs; a very large number when there is none)
+double cgroup_cpu_quota(const char* cgroup_root = "/sys/fs/cgroup", const char* proc_cgroup = "/proc/self/cgroup");
+
 }  // namespace pfa

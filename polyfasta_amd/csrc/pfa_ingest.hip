@@ -650,19 +650,19 @@ void uploader(pfa_ingest* g) {
 
 uint32_t auto_threads() {
   if (const char* e = getenv("PFA_THREADS")) { const long v = strtol(e, nullptr, 10); if (v > 0) return (uint32_t)std::min<long>(v, 256); }
-  cpu_set_t set;
-  uint32_t cpus = 1;
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = (uint32_t)std::max(1, CPU_COUNT(&set));
-  // the CPUs this process may use, shared with the other ranks of the node — unless the rank has already bound itself to
-  // its own share of them (dist.bind_to_gpu_node sets PFA_CPUS_ARE_MINE)
-  uint32_t local = 1, ranks = 1;
-  for (const char* var : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
-    if (const char* e = getenv(var)) { const long v = strtol(e, nullptr, 10); if (v > 0) { ranks = (uint32_t)v; break; } }
-  if (!getenv("PFA_CPUS_ARE_MINE")) local = ranks;
-  // measured (profiles/r03_e2e_16_vs_20_vs_24_threads.txt, six alternating rounds): 16 loaders 219-230 k alignments/s best / 193-217 k
-  // median; 20: 217-249 k / 187-205 k; 24: 180-239 k / 170-190 k; 28 and more collapse (profiles/r03_e2e_thread_sweep.txt): the
+  // The CPUs this rank may keep busy (pfa_fasta.cpp: cpu_share — affinity and the control group's CPU quota, shared out over
+  // the ranks of the node).  Round 4: the GPU boxes of this pool may run on 256 CPUs but have a quota of 16 CPU-seconds per
+  // second; 4 ranks x 16 loaders on such a box spent most of every 100 ms period frozen by the scheduler
+  // (profiles/r04_rank_rehearsals_one_gpu.txt).  One process inside that quota: 16 loaders use 14.8 CPUs and are never
+  // throttled — 218 / 213 k alignments/s against 205 / 198 k with 14 and 187 k with 12 (profiles/r04_e2e_cpu_budget.txt) — so
+  // nothing is held back for the uploader and the caller's thread (PFA_CPU_RESERVE=x does).
+  // At most 16 (profiles/r03_e2e_16_vs_20_vs_24_threads.txt, six alternating rounds): 16 loaders 219-230 k alignments/s best /
+  // 193-217 k median; 20: 217-249 k / 187-205 k; 24: 180-239 k / 170-190 k; 28 and more collapse (r03_e2e_thread_sweep.txt): the
   // host's read() is capped in aggregate, more loaders only wait for ring slots
-  return std::max(1u, std::min(16u, cpus / std::max(local, 1u)));
+  double reserve = 0.0;
+  if (const char* e = getenv("PFA_CPU_RESERVE")) reserve = atof(e);
+  const double room = cpu_share() - reserve;
+  return (uint32_t)std::max(1.0, std::min(16.0, room));
 }
 
 int ensure_dev(uint8_t** p, size_t* cap, size_t need) {
@@ -793,6 +793,27 @@ int pfa_ingest_open_dir(const char* dir, const pfa_ingest_opts* opts, pfa_ingest
     return rc;
   } catch (const std::bad_alloc&) {
     pfa::set_error("pfa_ingest_open_dir: out of host memory");
+    return PFA_ERR_NOMEM;
+  }
+}
+
+int pfa_ingest_open_names(const char* dir, const char* names_blob, const uint64_t* names_off, uint32_t n_files,
+                          const pfa_ingest_opts* opts, pfa_ingest** out) {
+  PFA_NEED_INIT();
+  if (!dir || !out || (n_files && (!names_blob || !names_off))) { pfa::set_error("pfa_ingest_open_names: NULL argument"); return PFA_ERR_ARG; }
+  *out = nullptr;
+  try {
+    const std::string prefix = std::string(dir) + "/";
+    std::vector<std::string> v;
+    v.reserve(n_files);
+    for (uint32_t i = 0; i < n_files; ++i) {
+      if (names_off[i + 1] < names_off[i]) { pfa::set_error("pfa_ingest_open_names: offsets of name %u run backwards", i); return PFA_ERR_ARG; }
+      v.emplace_back(prefix);
+      v.back().append(names_blob + names_off[i], (size_t)(names_off[i + 1] - names_off[i]));
+    }
+    return ingest_open_impl(std::move(v), opts, out);
+  } catch (const std::bad_alloc&) {
+    pfa::set_error("pfa_ingest_open_names: out of host memory");
     return PFA_ERR_NOMEM;
   }
 }

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "pfa_common.h"
+#include "pfa_host.h"
 #include "pfa_launch.h"
 #include "pfa_layout.h"
 
@@ -241,8 +242,13 @@ static int init_impl(int device) {
   PFA_HIP(hipSetDevice(device));
   // host waits spin instead of sleeping on an interrupt: a blocked wait was seen to return
   // up to 8 ms late on the GPU box, longer than a whole batch scan (hint only; ignored if the
-  // runtime already fixed its flags)
-  (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+  // runtime already fixed its flags) — unless this process is short of CPUs (several ranks inside one
+  // control group's CPU quota: every spinning wait is quota the loader threads do not get, and a group that
+  // uses its quota up is frozen until the 100 ms period ends): then waits sleep.  PFA_WAIT=spin|block overrides.
+  c.cpu_share = pfa::cpu_share();
+  c.spin_waits = c.cpu_share >= 12.0;
+  if (const char* e = getenv("PFA_WAIT")) c.spin_waits = strcmp(e, "block") != 0;
+  (void)hipSetDeviceFlags(c.spin_waits ? hipDeviceScheduleSpin : hipDeviceScheduleBlockingSync);
   (void)hipGetLastError();
   hipDeviceProp_t prop;
   PFA_HIP(hipGetDeviceProperties(&prop, device));
@@ -830,7 +836,9 @@ int pfa_plan_fetch(pfa_plan* p, pfa_result* results, uint32_t* sfs, uint32_t* sy
       }
       PFA_HIP(hipGetLastError());
       bool seen = false;
-      if (d_flag != nullptr) {
+      if (d_flag != nullptr && !pfa::ctx().spin_waits) {
+        p->fetch_ticket += 1u;      // (short of CPUs: no polling, the stream wait below sleeps)
+      } else if (d_flag != nullptr) {
         // poll the flag word (acquire: the slab reads below stay behind it) for at most 2 ms, then fall back
         p->fetch_ticket += 1u;
         const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);

@@ -148,6 +148,41 @@ class Ingest:
         self._bind_names(int(n.value))
         return self
 
+    @classmethod
+    def from_dir_shared(cls, directory, comm, keys=(), cds=False, **kw):
+        """`from_dir` for the ranks of a multi-GPU job: rank 0 lists and sorts the directory, the others take its name table
+        (one all-gather) — R processes walking one directory of 100 k entries at the same time serialise on the directory
+        (every rank's listing took 26 ms with 4 ranks, 51 ms with 6, against 5 ms alone), and every rank is certain to
+        number the files alike.  None on every rank when the library declines the directory (the caller's os.listdir then)."""
+        import struct
+        ing = cls.from_dir(directory, keys=keys, cds=cds, **kw) if comm.rank == 0 else None
+        mine = b""
+        if ing is not None:
+            n = len(ing.paths)
+            mine = struct.pack("<Q", n) + np.ascontiguousarray(ing.table.names_off[:n + 1]).tobytes() + np.ascontiguousarray(ing.table.names_blob).tobytes()
+        blob = comm.all_gather_bytes(mine)[0]
+        if comm.rank == 0 or not blob:
+            return ing
+        n = struct.unpack_from("<Q", blob)[0]
+        off = np.frombuffer(blob, dtype=np.uint64, count=n + 1, offset=8)
+        names = np.frombuffer(blob, dtype=np.uint8, offset=8 + 8 * (n + 1))
+        _lib.init()
+        lib = _lib.load()
+        self = cls.__new__(cls)
+        self.keys = [k.encode("utf-8", "surrogateescape") if isinstance(k, str) else bytes(k) for k in keys]
+        karr = (ctypes.c_char_p * max(len(self.keys), 1))(*self.keys)
+        o = _lib.IngestOptsC(n_threads=int(kw.get("threads", 0)), stride_align=int(kw.get("stride_align", 128)), unit_flags=_lib.PFA_FLAG_CDS if cds else 0,
+                             n_keys=len(self.keys), keys=karr, slot_bytes=int(kw.get("slot_bytes", 0)), n_slots=int(kw.get("n_slots", 0)), reserved=0)
+        h = ctypes.c_void_p()
+        self.handle = None
+        _lib.check(lib.pfa_ingest_open_names(os.fsencode(directory), _lib.ptr(np.ascontiguousarray(names)) if len(names) else None,
+                                             _lib.ptr(np.ascontiguousarray(off)), int(n), ctypes.byref(o), ctypes.byref(h)))
+        self.handle = h
+        self.cds = bool(cds)
+        self.paths = NativePaths(self, int(n))
+        self._bind_names(int(n))
+        return self
+
     def _bind_names(self, n):
         lib = _lib.load()
         blob, off = ctypes.c_void_p(), ctypes.c_void_p()

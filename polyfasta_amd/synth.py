@@ -126,6 +126,40 @@ def synth_alignment(seed: int, aln_index: int, n_sites: int, params: SynthParams
     return ASCII_ACGT[code.astype(np.int64)]
 
 
+_MANY_SALT = _U64(0x3A11E1E5C0FFEE01)
+_SUBSET_SALT = _U64(0x5B5E7F00DFACADE5)
+
+
+def many_allele_matrix(seed: int, n_rows: int, n_sites: int, alphabet: bytes) -> np.ndarray:
+    """uint8 matrix [N, L] for the many-row fixtures (tests/golden G10): every site draws 1-5 alleles from `alphabet`
+    (repeats merge) with cubed-random weights, so sites carry three and more alleles at frequencies from a handful of rows
+    to nearly all of them — second-largest counts far above any fixed number of SFS bins, per-site N^2 - sum c^2 above 32
+    bits once N passes ~92 000.  Integer arithmetic on splitmix64 hashes only (reproducible anywhere)."""
+    n, L = int(n_rows), int(n_sites)
+    syms = np.frombuffer(alphabet, dtype=np.uint8)
+    out = np.empty((n, L), dtype=np.uint8)
+    with np.errstate(over="ignore"):
+        key = splitmix64(_U64(seed) ^ _MANY_SALT)
+        rows = np.arange(n, dtype=_U64)
+        for s in range(L):
+            hs = splitmix64(key + _U64(s) * _ALN_MULT)
+            k = 1 + int(hs % _U64(5))
+            hj = splitmix64(hs + np.arange(1, 1 + k, dtype=_U64))
+            al = syms[(hj % _U64(len(syms))).astype(np.int64)]
+            x = (hj >> _U64(43)) & _U64(0x1FFFFF)                 # 21 bits: x^3 < 2^63
+            cum = np.cumsum(x * x * x + _U64(1 << 20))
+            v = splitmix64(splitmix64(hs ^ _MANY_SALT) + rows) % cum[-1]
+            out[:, s] = al[np.searchsorted(cum, v, side="right")]
+    return out
+
+
+def row_subset(seed: int, n_rows: int, frac: float) -> np.ndarray:
+    """ascending uint32 indices of about `frac` of the rows (hash-driven, reproducible): a population of a huge alignment"""
+    with np.errstate(over="ignore"):
+        h = splitmix64((_U64(seed) ^ _SUBSET_SALT) + np.arange(int(n_rows), dtype=_U64))
+    return np.flatnonzero((h & _U64(0xFFFF)) < _U64(int(frac * 65536))).astype(np.uint32)
+
+
 def inject_symbols(matrix: np.ndarray, seed: int, frac: float, alphabet: bytes) -> np.ndarray:
     """Overwrite about `frac` of the cells with symbols from `alphabet`
     (hash-driven, reproducible) — gaps, N, IUPAC codes, lower case."""

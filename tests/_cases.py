@@ -24,6 +24,33 @@ def matrix_from_gen(g):
     return m
 
 
+def g10_matrix(g):
+    """uint8 [N, L] of a G10 (many rows) case: the same recipe as gen_golden.g10_matrix"""
+    if g["kind"] == "many":
+        m = synth.many_allele_matrix(g["seed"], g["N"], g["L"], g["alphabet"].encode())
+    else:
+        m = synth.synth_alignment(g["seed"], 0, g["L"], synth.make_params(g["N"], g["theta"]), coding=g.get("coding", False))
+        if g.get("inject"):
+            m = synth.inject_symbols(m, g["inject"]["seed"], g["inject"]["frac"], g["inject"]["alphabet"].encode())
+    if g.get("subset"):
+        m = np.ascontiguousarray(m[synth.row_subset(g["subset"]["seed"], g["N"], g["subset"]["frac"])])
+    return m
+
+
+def g10_full_matrix_and_rows(g):
+    """(matrix of ALL rows, row subset or None): what a --pops unit of a huge alignment looks like to the ABI"""
+    if not g.get("subset"):
+        return g10_matrix(g), None
+    full = dict(g)
+    sub = full.pop("subset")
+    return g10_matrix(full), synth.row_subset(sub["seed"], g["N"], sub["frac"])
+
+
+def sparse_sfs(sfs):
+    """a folded SFS as the G10 records hold it"""
+    return {"len": len(sfs), "nz": [[i, int(c)] for i, c in enumerate(sfs) if c]}
+
+
 def dict_from_gen(g):
     return synth.to_dict(synth.headers_for(g["N"], g.get("pops", 0)), matrix_from_gen(g))
 

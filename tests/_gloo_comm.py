@@ -12,6 +12,10 @@ from polyfasta_amd import dist
 class GlooComm(dist.Comm):
     def __init__(self):
         self.rank, self.local_rank, self.world = dist.env_world()
+        # torch's intra-op pool is one OpenMP thread per CPU, and they spin after every op: on a 256-CPU box with a CPU quota
+        # of 16 the pools of four ranks froze the whole control group for most of every scheduler period (a 400 kB gather
+        # took 0.3-1.8 s; 3-16 ms with one thread).  The product's communicator (RCCL) has no such pool.
+        torch.set_num_threads(1)
         if not td.is_initialized():
             with dist.stdout_to_stderr():        # gloo announces its peers on stdout
                 td.init_process_group(backend="gloo")

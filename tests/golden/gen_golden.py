@@ -15,9 +15,8 @@ tests/golden/example_theta_0.01/ATTRIBUTION).
 
 Families: G1 examples, G2 synthetic grid, G3 odd symbols and
 FASTA syntax, G4 exhaustive codon-set tables, G5 coding alignments, G6
-populations, G7 command-line transcripts, G8 the BASELINE.json configurations, G9 sequences with
-non-ASCII characters
-at their full sizes.
+populations, G7 command-line transcripts, G8 the BASELINE.json configurations at their full sizes, G9 sequences
+with non-ASCII characters, G10 units of hundreds to 2^20 rows.
 """
 import contextlib
 import hashlib
@@ -534,7 +533,105 @@ def g9():
     dump("g9_unicode.json", out)
 
 
+# ------------------------------------------------------- G10 the many-row regime
+SYM = "ACGT" * 3 + "N-RY"
+
+
+def g10_matrix(g):
+    """the input of a G10 case from its generator parameters (tests/_cases.py: matrix_from_gen does the same)"""
+    if g["kind"] == "many":
+        m = synth.many_allele_matrix(g["seed"], g["N"], g["L"], g["alphabet"].encode())
+    else:
+        m = synth.synth_alignment(g["seed"], 0, g["L"], synth.make_params(g["N"], g["theta"]), coding=g.get("coding", False))
+        if g.get("inject"):
+            m = synth.inject_symbols(m, g["inject"]["seed"], g["inject"]["frac"], g["inject"]["alphabet"].encode())
+    if g.get("subset"):
+        m = np.ascontiguousarray(m[synth.row_subset(g["subset"]["seed"], g["N"], g["subset"]["frac"])])
+    return m
+
+
+def sparse(sfs):
+    return sfs if isinstance(sfs, str) or sfs is None else {"len": len(sfs), "nz": [[i, c] for i, c in enumerate(sfs) if c]}
+
+
+def g10():
+    """Units of hundreds to 2^20 rows — the row-chunked kernels, the 128-site coding kernel at 101-200 rows, 64-bit H and
+    the wide coding entries — pinned to the reference itself (it has no row limit: PolyFastA.py:252-261, :284-315):
+    getvarsites S and position hash, integer H, getsfs (sparse), both polymorphism tuples, and for coding cases the
+    getvarCDSsites 5-tuple and both CSV rows.  Both oracles are asserted against the reference here."""
+    import time
+    from oracle import c_oracle
+    non = [dict(kind="many", seed=1001, N=601, L=700, alphabet="ACGT"),
+           dict(kind="many", seed=1002, N=1000, L=333, alphabet=SYM),
+           dict(kind="synth", seed=1003, N=2048, L=512, theta=0.05, inject=dict(seed=5, frac=0.002, alphabet="-N")),
+           dict(kind="many", seed=1004, N=5000, L=333, alphabet=SYM),
+           dict(kind="many", seed=1005, N=5000, L=400, alphabet="ACGT"),
+           dict(kind="many", seed=1006, N=70000, L=64, alphabet=SYM),
+           dict(kind="many", seed=1007, N=70000, L=64, alphabet="ACGT"),
+           dict(kind="many", seed=1007, N=70000, L=64, alphabet="ACGT", subset=dict(seed=11, frac=0.95)),
+           dict(kind="many", seed=1008, N=1 << 20, L=16, alphabet="ACGT"),
+           dict(kind="many", seed=1009, N=1 << 20, L=16, alphabet="ACGT-N")]
+    cod = [dict(kind="many", seed=1101, N=128, L=333, alphabet="ACGT"),
+           dict(kind="synth", seed=1102, N=160, L=333, theta=0.05, coding=True),
+           dict(kind="many", seed=1103, N=200, L=333, alphabet=SYM),
+           dict(kind="synth", seed=1104, N=200, L=999, theta=0.03, coding=True),
+           dict(kind="many", seed=1105, N=601, L=333, alphabet="ACGT"),
+           dict(kind="synth", seed=1106, N=2049, L=333, theta=0.05, coding=True),
+           dict(kind="many", seed=1107, N=2049, L=333, alphabet=SYM),
+           dict(kind="many", seed=1108, N=5000, L=333, alphabet="ACGT"),
+           dict(kind="synth", seed=1109, N=5000, L=333, theta=0.05, coding=True, inject=dict(seed=6, frac=0.001, alphabet="-N")),
+           dict(kind="many", seed=1110, N=70000, L=66, alphabet=SYM),
+           dict(kind="many", seed=1111, N=70000, L=66, alphabet="ACGT"),
+           dict(kind="many", seed=1111, N=70000, L=66, alphabet="ACGT", subset=dict(seed=12, frac=0.95)),
+           dict(kind="many", seed=1112, N=1 << 20, L=15, alphabet="ACGT")]
+    out = []
+    for cds, gens in ((False, non), (True, cod)):
+        for g in gens:
+            t0 = time.perf_counter()
+            m = g10_matrix(g)
+            n, L = m.shape
+            d = synth.to_dict([f"s{i}" for i in range(n)], m)
+            rec = l1_record(d, L, check_oracle=n * L <= 5_000_000)      # (the pure-Python oracle: the cases it finishes in seconds)
+            rec["sfs"] = sparse(rec["sfs"])
+            o = c_oracle.scan(m, cds=cds, want_sites=True)
+            assert (o["S"], o["H"]) == (rec["S"], rec["H"]), (g, o["S"], o["H"], rec["S"], rec["H"])
+            assert sha1_ints(np.flatnonzero(o["h_site"])) == rec["pos_sha1"]
+            if rec["S"]:
+                if rec["sfs"] == "IndexError":
+                    assert o["sfs_bad"] > 0
+                else:
+                    assert o["sfs_bad"] == 0 and sparse(o["sfs"].tolist()) == rec["sfs"]
+            case = {"gen": g, "coding": cds, **rec}
+            if cds:
+                cs, s, nn, nstops, missing = ref.getvarCDSsites(d, L)
+                assert np.flatnonzero(o["labels"] == 1).tolist() == sorted(s) and np.flatnonzero(o["labels"] == 2).tolist() == sorted(nn)
+                assert (o["nstops"], 3 * o["missing_cols"]) == (nstops, missing) and close(o["count_syn"], cs, 1e-12)
+                rows = {}
+                for jc in (False, True):
+                    row = capture(ref.print_result, d, L, True, "", "a", "x.fa", "NA", True, 0, jc).rstrip("\n")
+                    rows["row_jc" if jc else "row"] = row
+                    assert_rows_close(orc.row_from_counts("x.fa", "NA", n, L, o, True, jc), row)
+                # H_S / H_N: the integer H of the variable columns at the S / N positions (PolyFastA.py:169-173)
+                pos, var = ref.getvarsites(d, L)
+                at = {p: i for i, p in enumerate(pos)}
+                hs = int_H([var[at[p]] for p in s if p in at])
+                hn = int_H([var[at[p]] for p in nn if p in at])
+                assert (o["H_S"], o["H_N"]) == (hs, hn)
+                case["cds"] = {"count_syn": cs, "S_sha1": sha1_ints(sorted(s)), "N_sha1": sha1_ints(sorted(nn)), "n_S": len(s), "n_N": len(nn),
+                               "seg_S": sum(1 for p in s if p in at), "seg_N": sum(1 for p in nn if p in at), "H_S": hs, "H_N": hn,
+                               "nstops": nstops, "missing": missing, **rows}
+                assert (o["seg_S"], o["seg_N"]) == (case["cds"]["seg_S"], case["cds"]["seg_N"])
+            else:
+                for jc, key in ((False, "poly"), (True, "poly_jc")):
+                    got = orc.polymorphism_from_counts(o["S"], o["H"], n, L, jc)
+                    assert all(close(x, y) for x, y in zip(got, rec[key])), (got, rec[key])
+            out.append(case)
+            print(f"  G10 {'coding' if cds else 'plain '} N={n} L={L} S={rec['S']} H={rec['H']} ({time.perf_counter() - t0:.1f} s)", flush=True)
+            del d
+    dump("g10_many_rows.json", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

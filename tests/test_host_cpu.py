@@ -498,3 +498,47 @@ def test_ranks_get_the_ipc_mode_whoever_launched_them(monkeypatch):
     for extra, want in (({"WORLD_SIZE": "8"}, "0"), ({"WORLD_SIZE": "8", "HSA_ENABLE_IPC_MODE_LEGACY": "1"}, "1"), ({}, "unset")):
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, **extra), timeout=120)
         assert p.returncode == 0 and p.stdout.strip() == want, (extra, p.stdout, p.stderr[-500:])
+
+
+def test_cpu_share_follows_the_control_group_quota(tmp_path):
+    """The loader pool and the spin-or-sleep choice go by the CPUs the process may keep BUSY: a container that may run on
+    256 CPUs with `cpu.max` = "1600000 100000" has 16.  cgroup v2 (own group and ancestors), v1, no limit; shared out over the
+    ranks of the node (checked in a child process: the environment decides)."""
+    import subprocess
+    import sys
+    lib = _lib.load()
+    # v2, limit on the group itself
+    r = tmp_path / "v2"
+    (r / "a" / "b").mkdir(parents=True)
+    (r / "cpu.max").write_text("max 100000\n")
+    (r / "a" / "cpu.max").write_text("max 100000\n")
+    (r / "a" / "b" / "cpu.max").write_text("1600000 100000\n")
+    pc = tmp_path / "cg2"
+    pc.write_text("0::/a/b\n")
+    assert lib.pfa_host_cpu_share(str(r).encode(), str(pc).encode()) == 16.0
+    # the tightest limit on the way up holds
+    (r / "a" / "cpu.max").write_text("250000 100000\n")
+    assert lib.pfa_host_cpu_share(str(r).encode(), str(pc).encode()) == 2.5
+    # a container's view: "0::/" and the limit at the mount point
+    pc.write_text("0::/\n")
+    (r / "cpu.max").write_text("400000 100000\n")
+    assert lib.pfa_host_cpu_share(str(r).encode(), str(pc).encode()) == 4.0
+    # v1
+    r1 = tmp_path / "v1"
+    (r1 / "cpu" / "docker" / "x").mkdir(parents=True)
+    (r1 / "cpu" / "docker" / "x" / "cpu.cfs_quota_us").write_text("800000\n")
+    (r1 / "cpu" / "docker" / "x" / "cpu.cfs_period_us").write_text("100000\n")
+    (r1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    (r1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    pc1 = tmp_path / "cg1"
+    pc1.write_text("12:pids:/docker/x\n4:cpu,cpuacct:/docker/x\n1:name=systemd:/docker/x\n")
+    assert lib.pfa_host_cpu_share(str(r1).encode(), str(pc1).encode()) == 8.0
+    # nothing to read: no limit
+    assert lib.pfa_host_cpu_share(str(tmp_path / "none").encode(), str(tmp_path / "none2").encode()) >= 1e8
+    # the share of one rank: PFA_CPUS wins; otherwise at most the CPUs it may run on, divided by the ranks of the node
+    code = ("import sys; sys.path.insert(0, %r)\nfrom polyfasta_amd import _lib\nprint(_lib.load().pfa_host_cpu_share(None, None))\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("PFA_CPUS", "LOCAL_WORLD_SIZE", "WORLD_SIZE", "PFA_CPUS_ARE_MINE")}
+    one = float(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=60).stdout)
+    four = float(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, LOCAL_WORLD_SIZE="4"), timeout=60).stdout)
+    forced = float(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, PFA_CPUS="3.5"), timeout=60).stdout)
+    assert 1.0 <= one <= len(os.sched_getaffinity(0)) and four == max(1.0, one / 4) and forced == 3.5

@@ -205,3 +205,61 @@ def test_rows_from_integer_summaries_equal_the_reference_rows():
             rows = [i for i, h in enumerate(d) if pop in h]
             o = c_oracle.scan(m, rows=rows, cds=cds == "cds=1")
             C.rows_close(orc.row_from_counts("x.fa", pop, len(rows), case["gen"]["L"], o, cds == "cds=1", jc == "jc=1"), want, rel=1e-10, rel_jc=1e-10)
+
+
+def _g10_cases(max_cells=None):
+    return [c for c in C.load("g10_many_rows.json") if max_cells is None or c["N"] * c["L"] <= max_cells]
+
+
+def test_many_rows_g10_c_oracle():
+    """G10: units of 128 to 2^20 rows frozen from the reference (no row limit there: PolyFastA.py:252-261, :284-315) — the
+    regime where only the C oracle checks the row-chunked kernels.  S, position hash, integer H (above 32 bits per SITE from
+    ~92 k rows: the truncation the C oracle had in round 3), folded SFS, both polymorphism tuples through the checker's
+    finishing math, and for coding cases the getvarCDSsites tuple, the S / N splits and both CSV rows."""
+    for c in _g10_cases():
+        m = C.g10_matrix(c["gen"])
+        assert m.shape == (c["N"], c["L"])
+        o = c_oracle.scan(m, cds=c["coding"], want_sites=True)
+        assert (o["S"], o["H"]) == (c["S"], c["H"]), c["gen"]
+        pos = np.flatnonzero(o["h_site"])
+        assert C.sha1_ints(pos) == c["pos_sha1"] and pos[:24].tolist() == c["pos_head"]
+        if c["S"]:
+            if c["sfs"] == "IndexError":
+                assert o["sfs_bad"] > 0
+            else:
+                assert o["sfs_bad"] == 0 and C.sparse_sfs(o["sfs"].tolist()) == c["sfs"]
+        for jc, key in ((False, "poly"), (True, "poly_jc")):
+            got = orc.polymorphism_from_counts(o["S"], o["H"], c["N"], c["L"], jc)
+            assert got[0] == c[key][0] and all(C.close(x, y, REL) for x, y in zip(got[1:], c[key][1:])), (c["gen"], got, c[key])
+        if c["coding"]:
+            k = c["cds"]
+            assert C.sha1_ints(np.flatnonzero(o["labels"] == 1)) == k["S_sha1"] and C.sha1_ints(np.flatnonzero(o["labels"] == 2)) == k["N_sha1"]
+            assert (o["seg_S"], o["seg_N"], o["H_S"], o["H_N"], o["nstops"], 3 * o["missing_cols"]) == \
+                   (k["seg_S"], k["seg_N"], k["H_S"], k["H_N"], k["nstops"], k["missing"]), c["gen"]
+            assert C.close(o["count_syn"], k["count_syn"], 1e-12)
+            for jc, key in ((False, "row"), (True, "row_jc")):
+                C.rows_close(orc.row_from_counts("x.fa", "NA", c["N"], c["L"], o, True, jc), k[key], rel=1e-10, rel_jc=1e-10)
+        # a subset case through the row-index form of the oracle as well (what the GPU tests compare with)
+        if c["gen"].get("subset"):
+            full, rows = C.g10_full_matrix_and_rows(c["gen"])
+            o2 = c_oracle.scan(full, rows=rows, cds=c["coding"])
+            assert (o2["S"], o2["H"], o2["sfs"].tolist()) == (o["S"], o["H"], o["sfs"].tolist())
+
+
+def test_many_rows_g10_python_oracle():
+    """the pure-Python restatement on the G10 cases it finishes in seconds (up to 70 000 rows)"""
+    for c in _g10_cases(max_cells=5_000_000):
+        m = C.g10_matrix(c["gen"])
+        d = {f"s{i}": bytes(r).decode("latin-1") for i, r in enumerate(m)}
+        pos, var = orc.getvarsites(d, c["L"])
+        assert len(var) == c["S"] and C.sha1_ints(pos) == c["pos_sha1"]
+        summ = orc.integer_summary(d, c["L"])
+        assert summ["H"] == c["H"]
+        if c["S"]:
+            assert ("IndexError" if summ["sfs"] is None else C.sparse_sfs(summ["sfs"])) == c["sfs"]
+        if c["coding"] and c["N"] <= 5000:
+            k = c["cds"]
+            cs, s, n, nstops, missing = orc.getvarCDSsites(d, c["L"])
+            assert C.close(cs, k["count_syn"], 1e-12) and C.sha1_ints(sorted(s)) == k["S_sha1"] and C.sha1_ints(sorted(n)) == k["N_sha1"]
+            assert (nstops, missing) == (k["nstops"], k["missing"])
+            C.rows_close(orc.result_row(d, c["L"], True, "x.fa", "NA", True), k["row_jc"], rel=1e-10, rel_jc=1e-10)
