@@ -759,7 +759,10 @@ def main():
         # doing when the time ran out.
         import threading
 
+        fired = threading.Event()
+
         def bail():
+            fired.set()
             print(f"bench.py: rank {rank} of {world}: the N > 1 end-to-end leg did not finish within {args.e2e_ranks_timeout} s; "
                   f"last stage: {ranks_progress['stage']}", file=sys.stderr, flush=True)
             if rank == 0:
@@ -782,6 +785,8 @@ def main():
             ranks_progress["stage"] += f" -> {type(e).__name__}: {e}"
             dog.join()
         dog.cancel()
+        if fired.is_set():      # the time ran out while the leg was finishing: the watchdog's verdict stands (it ends the process)
+            dog.join()
         if rank == 0:
             line["end_to_end"] = e2e_ranks
             if "error" not in e2e_ranks:

@@ -166,7 +166,9 @@ struct Cache {
   uint8_t* d_text = nullptr; size_t d_text_cap = 0;
   uint8_t* d_packed = nullptr; size_t d_packed_cap = 0;
   uint8_t* d_segs = nullptr; size_t d_segs_cap = 0;
-  Pinned stage;   // segs + bad words of one batch
+  Pinned stage;   // segs + bad words of one batch: parked here between ingests; an open ingest holds its own (two ingests open
+                  // at once must not share it: the second one's next() would clear the first one's flags for bytes >= 0x80
+                  // before its caller has fetched them, and rewrite segments whose H2D copy is still in flight)
   void release() {
     std::lock_guard<std::mutex> g(mu);
     for (Pinned& p : pinned) (void)hipHostFree(p.h);
@@ -259,6 +261,7 @@ struct pfa_ingest {
   std::vector<int32_t> b_status;
   std::vector<pfa_desc> b_descs;
   std::vector<pfa::Pinned> big_pinned_done;   // pinned buffers of oversized files whose copy has completed
+  pfa::Pinned stage;                          // segments + per-file flags of the current batch (pinned; from / back to the cache)
   std::vector<uint8_t*> big_dev;              // device buffers of oversized files of the current batch
   uint32_t* bad_words = nullptr;
   bool launched = false;                      // something of the current batch sits on the context stream
@@ -940,18 +943,22 @@ int pfa_ingest_next(pfa_ingest* g, pfa_ingest_batch* out) {
     }
     // staging: the segments and the per-file `bad` words of this batch, in pinned memory
     const size_t seg_bytes = (size_t)n_segs * sizeof(pfa::Seg), bad_off = pfa::up256(seg_bytes), stage_need = bad_off + pfa::up256((size_t)nf * 4u + 4u);
-    {
-      std::lock_guard<std::mutex> ck(pfa::g_cache.mu);
-      if (pfa::g_cache.stage.cap < stage_need) {
-        if (pfa::g_cache.stage.h) (void)hipHostFree(pfa::g_cache.stage.h);
-        pfa::g_cache.stage = pfa::Pinned();
+    if (g->stage.cap < stage_need) {
+      // (the previous batch of THIS ingest is done with it: release_batch() above has waited for its repack)
+      if (!g->stage.h) {
+        std::lock_guard<std::mutex> ck(pfa::g_cache.mu);
+        if (pfa::g_cache.stage.cap >= stage_need) { g->stage = pfa::g_cache.stage; pfa::g_cache.stage = pfa::Pinned(); }
+      }
+      if (g->stage.cap < stage_need) {
+        if (g->stage.h) (void)hipHostFree(g->stage.h);
+        g->stage = pfa::Pinned();
         const size_t want = stage_need + stage_need / 2 + 65536;
-        if (hipHostMalloc((void**)&pfa::g_cache.stage.h, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pfa::set_error("pfa_ingest_next: cannot allocate the staging buffer"); return PFA_ERR_NOMEM; }
-        pfa::g_cache.stage.cap = want;
+        if (hipHostMalloc((void**)&g->stage.h, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pfa::set_error("pfa_ingest_next: cannot allocate the staging buffer"); return PFA_ERR_NOMEM; }
+        g->stage.cap = want;
       }
     }
-    pfa::Seg* const h_segs = reinterpret_cast<pfa::Seg*>(pfa::g_cache.stage.h);
-    g->bad_words = reinterpret_cast<uint32_t*>(pfa::g_cache.stage.h + bad_off);
+    pfa::Seg* const h_segs = reinterpret_cast<pfa::Seg*>(g->stage.h);
+    g->bad_words = reinterpret_cast<uint32_t*>(g->stage.h + bad_off);
     memset(g->bad_words, 0, (size_t)nf * 4u + 4u);
     // (direct mode: every use is an allocation of its own and the segments carry absolute addresses)
     const uint8_t* const text_base = g->direct ? nullptr : uv.front().big ? uv.front().d : g->d_text;
@@ -1130,6 +1137,16 @@ void pfa_ingest_close(pfa_ingest* g) {
   for (hipEvent_t e : g->batch_ev) if (e) (void)hipEventDestroy(e);
   for (pfa::Pinned& p : g->big_pinned_done) pfa::give_pinned(p);
   for (pfa::Pinned& p : g->slots) pfa::give_pinned(p);
+  if (g->stage.h) {
+    std::lock_guard<std::mutex> ck(pfa::g_cache.mu);
+    if (live && pfa::g_cache.stage.cap < g->stage.cap) {
+      if (pfa::g_cache.stage.h) (void)hipHostFree(pfa::g_cache.stage.h);
+      pfa::g_cache.stage = g->stage;
+    } else {
+      (void)hipHostFree(g->stage.h);
+    }
+    g->stage = pfa::Pinned();
+  }
   if (g->d_text) {
     std::lock_guard<std::mutex> ck(pfa::g_cache.mu);
     if (live && pfa::g_cache.d_text_cap < g->d_text_cap) {

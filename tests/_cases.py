@@ -79,6 +79,31 @@ def rows_close(got, want, rel=1e-9, rel_jc=1e-6, jc=False, abs_d=1e-9):
     return True
 
 
+def row_matches(got, want, cds, jc):
+    """One CSV row, column by column: text columns and integers equal; theta and D to 1e-9 relative (D, a cancelling
+    difference, also 1e-9 absolute); pi to 1e-9 — 1e-6 when Jukes-Cantor corrected (BASELINE.json).  Returns None or the
+    name of the first column that differs."""
+    fa, fb = got.split(","), want.split(",")
+    if len(fa) != len(fb) or len(fa) != (14 if cds else 8):
+        return "column count"
+    names = ("file,sites_S,sites_N,pop,N,seg_sites_S,seg_sites_N,pi_S,pi_N,theta_S,theta_N,tajimasD_S,tajimasD_N,nstops" if cds
+             else "file,seqlen,pop,N,seg_sites,pi,theta,tajimasD").split(",")
+    for name, x, y in zip(names, fa, fb):
+        if x == y:
+            continue
+        if not name.startswith(("pi", "theta", "tajimasD", "sites_")):
+            return name
+        try:
+            fx, fy = float(x), float(y)
+        except ValueError:
+            return name
+        tol = 1e-6 if (jc and name.startswith("pi")) else 1e-9
+        if abs(fx - fy) <= tol * max(abs(fx), abs(fy)) or (name.startswith("tajimasD") and abs(fx - fy) <= 1e-9):
+            continue
+        return name
+    return None
+
+
 def sha1_ints(xs):
     import hashlib
     return hashlib.sha1(np.asarray(xs, dtype=np.int64).tobytes()).hexdigest()

@@ -67,6 +67,7 @@ struct pfa_plan {
   std::vector<uint32_t> ridx;
   const uint8_t* bases = nullptr;
   uint64_t n_bytes = 0;
+  std::vector<uint8_t> snap;   // the matrices as the "scan" saw them: copied in stream order, as a kernel would read them
 };
 extern "C" int pfa_plan_create(const pfa_desc* descs, uint32_t n, const uint32_t* row_idx, size_t n_row_idx, uint64_t n_bytes, uint32_t, pfa_plan** out) {
   pfa_plan* p = new pfa_plan();
@@ -78,6 +79,8 @@ extern "C" int pfa_plan_create(const pfa_desc* descs, uint32_t n, const uint32_t
 }
 extern "C" int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int) {
   p->bases = d_bases;
+  // (another ingest's next batch may overwrite the shared matrix buffer behind this point of the stream, as on the card)
+  pfa::ctx().stream->push([p, d_bases]() { p->snap.assign(d_bases, d_bases + p->n_bytes); });
   return PFA_OK;
 }
 extern "C" void pfa_plan_destroy(pfa_plan* p) {
@@ -162,6 +165,55 @@ int main(int argc, char** argv) {
   pfa::ctx().device = 0;
   (void)hipStreamCreateWithFlags(&pfa::ctx().stream, hipStreamNonBlocking);
   uint64_t files_checked = 0, bytes_checked = 0;
+  // every file of a batch against the independent reading
+  auto check_batch = [&](const pfa_ingest_batch& b, const std::vector<Expect>& want, const std::vector<std::string>& paths, const pfa_ingest_opts& o,
+                         const char* const* keys, std::vector<int>& seen, int round) {
+      uint32_t u = 0;
+      for (uint32_t f = 0; f < b.n_files; ++f) {
+        const uint32_t gi = b.file_idx[f];
+        const Expect& e = want[gi];
+        seen[gi] += 1;
+        CHECK(b.status[f] == e.status, "round %d file %u (%s): status %d, expected %d", round, gi, paths[gi].c_str(), b.status[f], e.status);
+        if (e.status != 0) continue;
+        CHECK(b.n_rows[f] == e.rows.size() && b.n_sites[f] == e.rows[0].size(), "round %d file %u: %u x %u, expected %zu x %zu", round, gi, b.n_rows[f],
+              b.n_sites[f], e.rows.size(), e.rows[0].size());
+        CHECK((b.bad_bytes[f] != 0) == e.bad, "round %d file %u: bad flag %u, expected %d", round, gi, b.bad_bytes[f], (int)e.bad);
+        std::vector<std::vector<uint32_t>> sel;               // expected units of this file: row lists
+        if (o.n_keys == 0) {
+          std::vector<uint32_t> all(e.rows.size());
+          for (uint32_t r = 0; r < all.size(); ++r) all[r] = r;
+          sel.push_back(all);
+        } else {
+          for (uint32_t k = 0; k < o.n_keys; ++k) {
+            std::vector<uint32_t> rows;
+            for (uint32_t r = 0; r < e.names.size(); ++r)
+              if (e.names[r].find(keys[k]) != std::string::npos) rows.push_back(r);
+            CHECK(b.key_rows[(size_t)f * o.n_keys + k] == rows.size(), "round %d file %u key %u: %u rows, expected %zu", round, gi, k,
+                  b.key_rows[(size_t)f * o.n_keys + k], rows.size());
+            if (!rows.empty()) sel.push_back(rows);
+          }
+        }
+        for (const auto& rows : sel) {
+          CHECK(u < b.n_units && b.unit_file[u] == f && b.unit_rows[u] == rows.size(), "round %d file %u: unit table", round, gi);
+          const pfa_desc& d = b.plan->descs[u];
+          // a unit is a matrix of its own: all records of the file, or — population split — the records its key names, in record order
+          CHECK(d.n_rows == rows.size() && d.n_sites == e.rows[0].size() && d.mat_rows == rows.size() && d.row_idx_off == PFA_NO_ROW_IDX &&
+                    d.row_stride % 16 == 0 && d.base_off % 256 == 0 && d.base_off + (uint64_t)d.mat_rows * d.row_stride <= b.plan->n_bytes,
+                "round %d file %u: descriptor", round, gi);
+          for (uint32_t k = 0; k < rows.size(); ++k) {
+            const uint32_t r = rows[k];
+            const uint8_t* got = b.plan->snap.data() + d.base_off + (uint64_t)k * d.row_stride;
+            CHECK(memcmp(got, e.rows[r].data(), d.n_sites) == 0, "round %d file %u row %u: bytes differ (threads %u, slot %llu)", round, gi, r,
+                  o.n_threads, (unsigned long long)o.slot_bytes);
+            for (uint32_t c = d.n_sites; c < d.row_stride && d.n_sites; ++c) CHECK(got[c] == 0, "round %d file %u row %u: padding", round, gi, r);
+            bytes_checked += d.n_sites;
+          }
+          ++u;
+        }
+        ++files_checked;
+      }
+      CHECK(u == b.n_units, "round %d: %u units walked, batch holds %u", round, u, b.n_units);
+  };
   for (int round = 0; round < rounds; ++round) {
     // ---- a directory of awkward files
     const uint32_t n_files = round % 5 == 4 ? 1 + below(4) : 20 + below(60);      // (a handful of files: the ingest's direct mode)
@@ -212,58 +264,55 @@ int main(int argc, char** argv) {
       CHECK(rc >= 0, "next: %s", g_err);
       if (rc == 0) break;
       (void)hipStreamSynchronize(pfa::ctx().stream);          // the "fetch": repack and scan are done
-      // ---- every file of the batch against the independent reading
-      uint32_t u = 0;
-      for (uint32_t f = 0; f < b.n_files; ++f) {
-        const uint32_t gi = b.file_idx[f];
-        const Expect& e = want[gi];
-        seen[gi] += 1;
-        CHECK(b.status[f] == e.status, "round %d file %u (%s): status %d, expected %d", round, gi, paths[gi].c_str(), b.status[f], e.status);
-        if (e.status != 0) continue;
-        CHECK(b.n_rows[f] == e.rows.size() && b.n_sites[f] == e.rows[0].size(), "round %d file %u: %u x %u, expected %zu x %zu", round, gi, b.n_rows[f],
-              b.n_sites[f], e.rows.size(), e.rows[0].size());
-        CHECK((b.bad_bytes[f] != 0) == e.bad, "round %d file %u: bad flag %u, expected %d", round, gi, b.bad_bytes[f], (int)e.bad);
-        std::vector<std::vector<uint32_t>> sel;               // expected units of this file: row lists
-        if (o.n_keys == 0) {
-          std::vector<uint32_t> all(e.rows.size());
-          for (uint32_t r = 0; r < all.size(); ++r) all[r] = r;
-          sel.push_back(all);
-        } else {
-          for (uint32_t k = 0; k < o.n_keys; ++k) {
-            std::vector<uint32_t> rows;
-            for (uint32_t r = 0; r < e.names.size(); ++r)
-              if (e.names[r].find(keys[k]) != std::string::npos) rows.push_back(r);
-            CHECK(b.key_rows[(size_t)f * o.n_keys + k] == rows.size(), "round %d file %u key %u: %u rows, expected %zu", round, gi, k,
-                  b.key_rows[(size_t)f * o.n_keys + k], rows.size());
-            if (!rows.empty()) sel.push_back(rows);
-          }
-        }
-        for (const auto& rows : sel) {
-          CHECK(u < b.n_units && b.unit_file[u] == f && b.unit_rows[u] == rows.size(), "round %d file %u: unit table", round, gi);
-          const pfa_desc& d = b.plan->descs[u];
-          // a unit is a matrix of its own: all records of the file, or — population split — the records its key names, in record order
-          CHECK(d.n_rows == rows.size() && d.n_sites == e.rows[0].size() && d.mat_rows == rows.size() && d.row_idx_off == PFA_NO_ROW_IDX &&
-                    d.row_stride % 16 == 0 && d.base_off % 256 == 0 && d.base_off + (uint64_t)d.mat_rows * d.row_stride <= b.plan->n_bytes,
-                "round %d file %u: descriptor", round, gi);
-          for (uint32_t k = 0; k < rows.size(); ++k) {
-            const uint32_t r = rows[k];
-            const uint8_t* got = b.plan->bases + d.base_off + (uint64_t)k * d.row_stride;
-            CHECK(memcmp(got, e.rows[r].data(), d.n_sites) == 0, "round %d file %u row %u: bytes differ (threads %u, slot %llu)", round, gi, r,
-                  o.n_threads, (unsigned long long)o.slot_bytes);
-            for (uint32_t c = d.n_sites; c < d.row_stride && d.n_sites; ++c) CHECK(got[c] == 0, "round %d file %u row %u: padding", round, gi, r);
-            bytes_checked += d.n_sites;
-          }
-          ++u;
-        }
-        ++files_checked;
-      }
-      CHECK(u == b.n_units, "round %d: %u units walked, batch holds %u", round, u, b.n_units);
+      check_batch(b, want, paths, o, keys, seen, round);
     }
     for (uint32_t i = 0; i < n_files; ++i) CHECK(seen[i] == 1, "round %d: file %u handed out %d times", round, i, seen[i]);
     double st[8];
     CHECK(pfa_ingest_stats(ing, st) == PFA_OK, "stats");
     pfa_ingest_close(ing);
     for (auto& p : paths) { unlink(p.c_str()); rmdir(p.c_str()); }
+  }
+  // ---- two ingests open at once, their batches taken alternately (the API allows it): B's next() runs between A's next()
+  // and A's "fetch" — A's flags for bytes >= 0x80 and A's matrices must be what A's files say (each ingest stages its
+  // segments and flags in a buffer of its own; the matrix buffer is shared in stream order, as on the card)
+  for (int round = 0; round < std::max(2, rounds / 3); ++round) {
+    std::vector<std::string> paths[2];
+    std::vector<Expect> want[2];
+    for (int w = 0; w < 2; ++w)
+      for (uint32_t i = 0; i < 24; ++i) {
+        std::string p = dir + "/x" + std::to_string(round) + "_" + std::to_string(w) + "_f" + std::to_string(i) + ".fa";
+        want[w].push_back(write_file(p, (w == 0 && i % 5 == 2) ? 4 : (i == 7 ? 3 : 1)));      // A: every fifth file holds a byte >= 0x80
+        paths[w].push_back(p);
+      }
+    pfa_ingest_opts o{};
+    o.n_threads = 1 + below(8);
+    o.stride_align = 128;
+    o.slot_bytes = 64u << 10;
+    o.n_slots = 3;
+    const char* keys[1] = {""};
+    pfa_ingest* ing[2] = {nullptr, nullptr};
+    std::vector<int> seen[2] = {std::vector<int>(24, 0), std::vector<int>(24, 0)};
+    for (int w = 0; w < 2; ++w) {
+      std::vector<const char*> cp;
+      for (auto& p : paths[w]) cp.push_back(p.c_str());
+      CHECK(pfa_ingest_open(cp.data(), 24, &o, &ing[w]) == PFA_OK, "%s", g_err);
+      CHECK(pfa_ingest_feed(ing[w], nullptr, 24, 1) == PFA_OK, "%s", g_err);
+    }
+    bool live[2] = {true, true};
+    while (live[0] || live[1]) {
+      pfa_ingest_batch b[2];
+      int rc[2] = {0, 0};
+      for (int w = 0; w < 2; ++w)
+        if (live[w]) { rc[w] = pfa_ingest_next(ing[w], &b[w]); CHECK(rc[w] >= 0, "interleaved next: %s", g_err); live[w] = rc[w] == 1; }
+      (void)hipStreamSynchronize(pfa::ctx().stream);
+      for (int w = 0; w < 2; ++w)
+        if (rc[w] == 1) check_batch(b[w], want[w], paths[w], o, keys, seen[w], 1000 + round);
+    }
+    for (int w = 0; w < 2; ++w) {
+      for (uint32_t i = 0; i < 24; ++i) CHECK(seen[w][i] == 1, "interleaved round %d: file %u of ingest %d handed out %d times", round, i, w, seen[w][i]);
+      pfa_ingest_close(ing[w]);
+      for (auto& p : paths[w]) unlink(p.c_str());
+    }
   }
   pfa::ingest_release_cache();
   (void)hipStreamDestroy(pfa::ctx().stream);

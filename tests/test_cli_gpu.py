@@ -291,3 +291,85 @@ def test_sequences_with_non_ascii_characters(gpu, tmp_path, monkeypatch):
     assert pa == po and [list(c) for c in va] == [list(c) for c in vo]
     for x, y in zip(api.polymorphism(va, 60, False), orc.polymorphism(vo, 60, False)):
         assert x == y or abs(x - y) <= 1e-9 * abs(y)
+
+
+def test_directory_scale_every_row_every_column(gpu, tmp_path, monkeypatch):
+    """The streaming ingest at directory scale in the coding and population modes (PolyFastA.py:122-134, :165-180): 2 048
+    files of 50 x 9 000 in-frame CDS with pop1_* / pop2_* headers — among them one with N's, one in lower case, one wrapped
+    at 60 columns, one with unequal lengths, one with a premature stop codon — through 1 MiB slots and 16 loader threads
+    (many batches, files placed in whatever order the loaders finish).  `-p pop1,pop2 --cds --jc`, `--cds` and
+    `-p pop2,pop1`: EVERY row, ALL 14 / 8 columns against the checker (C oracle integers + its own finishing math):
+    text and integers equal, floats 1e-9, Jukes-Cantor pi 1e-6."""
+    import ctypes
+    import numpy as np
+    from oracle import c_oracle
+    from oracle import polyfasta_oracle as orc
+    from polyfasta_amd import _lib, scan
+    monkeypatch.setenv("PFA_INGEST_SLOT_BYTES", str(1 << 20))
+    monkeypatch.setenv("PFA_THREADS", "16")
+    M, N, L = 2048, 50, 9000
+    root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (3 << 30) else str(tmp_path)
+    d = os.path.join(root, f"pfa_dirscale_{os.getpid()}")
+    os.makedirs(d)
+    try:
+        p = synth.make_params(N, 0.01)
+        stride = scan.row_stride_for(L, 128)
+        sp = _lib.SynthParamsC(seed=404, first_aln=0, n_aln=M, n_rows=N, n_sites=L, row_stride=stride, seg_thresh=p.seg_thresh,
+                               tri_thresh=p.tri_thresh, n_units=len(p.units), coding=1)
+        bases = np.zeros(M * N * stride, dtype=np.uint8)
+        _lib.check(_lib.load().pfa_synth_fill_host(_lib.ptr(bases), ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(p.cdf)),
+                                                   _lib.ptr(np.ascontiguousarray(p.units))))
+        mats = bases.reshape(M, N, stride)[:, :, :L]
+        hdr = synth.headers_for(N, 2)
+        odd = {"with_N": 77, "lower": 300, "wrapped": 901, "unequal": 1500, "stop": 2047}
+        m = mats[odd["with_N"]]
+        m[3, 100:106] = ord("N")
+        m[40, 4000] = ord("N")
+        m = mats[odd["stop"]]
+        m[::2, 300:303] = np.frombuffer(b"TAA", dtype=np.uint8)        # a premature stop in every pop1 row
+        for i in range(M):
+            rows = [mats[i][r].tobytes() for r in range(N)]
+            if i == odd["lower"]:
+                rows = [x.lower() for x in rows]
+            if i == odd["wrapped"]:
+                rows = [b"\n".join(x[k:k + 60] for k in range(0, L, 60)) for x in rows]
+            if i == odd["unequal"]:
+                rows[7] = rows[7][:-3]
+            with open(os.path.join(d, f"cds{i:05d}.fa"), "wb") as fh:
+                fh.write(b"".join(b">" + h.encode() + b"\n" + x + b"\n" for h, x in zip(hdr, rows)))
+        pop_rows = {"pop1": np.arange(0, N, 2, dtype=np.uint32), "pop2": np.arange(1, N, 2, dtype=np.uint32)}
+        cache = {}
+
+        def want_rows(keys, cds, jc):
+            out = []
+            for i in range(M):
+                name = f"cds{i:05d}.fa"
+                if i == odd["unequal"]:
+                    out.append(f"# Sequences do not have the same length: {name}")
+                    continue
+                for key in keys or [None]:
+                    ck = (i, key, cds)
+                    if ck not in cache:
+                        cache[ck] = c_oracle.scan(mats[i], rows=None if key is None else pop_rows[key], cds=cds)
+                    n = N if key is None else len(pop_rows[key])
+                    out.append(orc.row_from_counts(name, key or "NA", n, L, cache[ck], cds, jc))
+            return out
+
+        for argv, keys, cds, jc in ((["-p", "pop1,pop2", "--cds", "--jc"], ["pop1", "pop2"], True, True), (["--cds"], None, True, False),
+                                    (["-p", "pop2,pop1"], ["pop2", "pop1"], False, False)):
+            rc, out = run_cli(["-d", d, "-s"] + argv)
+            assert rc == 0
+            got = out.rstrip("\n").split("\n")
+            want = want_rows(keys, cds, jc)
+            assert len(got) == len(want), (argv, len(got), len(want))
+            assert cli.last_stats["batches"] >= 64 and cli.last_stats["loader_threads"] == 16, cli.last_stats
+            bad = [(a, b, C.row_matches(a, b, cds, jc)) for a, b in zip(got, want) if a != b and (b.startswith("#") or C.row_matches(a, b, cds, jc))]
+            assert not bad, (argv, len(bad), bad[:3])
+        # the odd files did what they were meant to: the stop is counted, the N's make unclean codons, every file has variation
+        stop_row = [ln for ln in out.split("\n") if ln.startswith(f"cds{odd['stop']:05d}.fa")]
+        assert len(stop_row) == 2
+        rc, out = run_cli(["-d", d, "-s", "--cds", "-p", "pop1"])
+        f = [ln for ln in out.split("\n") if ln.startswith(f"cds{odd['stop']:05d}.fa")][0].split(",")
+        assert int(f[13]) >= 1
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
