@@ -425,10 +425,11 @@ META_DTYPE = np.dtype([("fidx", "<u4"), ("key", "<u4"), ("n_rows", "<u4"), ("n_s
 
 
 class RowBlock:
-    def __init__(self, meta, rec, syn=None, sfs=None, specials=None):
+    def __init__(self, meta, rec, syn=None, sfs=None, specials=None, io_error=None):
         self.meta, self.rec, self.syn = meta, rec, syn
         self.sfs = sfs                    # per unit: list of bins, or None (--sfs only)
         self.specials = specials or []    # (fidx, sub, kind, text); sub orders the lines of one file
+        self.io_error = io_error          # smallest index of a file that could not be read (the job dies THERE, PolyFastA.py:239), or None
 
     @staticmethod
     def concat(blocks, coding):
@@ -494,13 +495,15 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
     specials = []
     extra = []      # rows of files read as text (non-ASCII sequence characters)
     keep = None
+    io_error = None
     bad = b.bad != 0 if b.bad is not None and len(b.bad) else np.zeros(b.n_files, dtype=bool)
     if not b.regular or bad.any():
         st = b.status
         if (st == PFA_ERR_IO).any():
-            path = paths[int(b.file_idx[int(np.flatnonzero(st == PFA_ERR_IO)[0])])]
-            open(path, "rb").close()          # raises the OSError the reference would raise (PolyFastA.py:239)
-            raise OSError(f"cannot read {path}")
+            # a file that cannot be read (a subdirectory inside --dir, a vanished or unreadable file): the reference prints every
+            # row before it and dies with the OSError at its open() (PolyFastA.py:104-108, :239); the caller does the same
+            # (run_files: rows of the files below it, flush, then raise_unreadable).  Such files yield no rows here.
+            io_error = int(b.file_idx[st == PFA_ERR_IO].min())
         bad = bad | (st == PFA_FILE_UNSUPPORTED)      # unequal BYTE lengths and non-ASCII characters: the loader could not tell
         odd = (st != 0) | bad
         if args.cds:
@@ -511,6 +514,8 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
             fidx = int(b.file_idx[k])
             path = paths[fidx]
             name = path.split("/")[-1]
+            if st[k] == PFA_ERR_IO:
+                continue
             if st[k] == PFA_FILE_NOT_FASTA:
                 specials.append((fidx, 0, "stdout", f"# file {path} is not FASTA!"))                        # :247 (always stdout)
             elif st[k] == PFA_FILE_UNEQUAL:
@@ -557,7 +562,14 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
             syn = more if syn is None else np.concatenate([syn, more])
         if args.sfs:
             sfs = (sfs or []) + [u[6] for u in extra]
-    return RowBlock(meta, res, syn, sfs, specials)
+    return RowBlock(meta, res, syn, sfs, specials, io_error)
+
+
+def raise_unreadable(path):
+    """the OSError the reference dies with at its open() of this path (PolyFastA.py:239): IsADirectoryError, FileNotFoundError,
+    PermissionError ..."""
+    open(path, "r").close()
+    raise OSError(f"cannot read {path}")
 
 
 def block_events(blk, paths, keys):
@@ -689,6 +701,7 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
         # finish), so rows wait in `kept` until every file before them has arrived
         arrived = np.zeros(len(paths) + 1, dtype=bool)
         upto = 0
+        io_fail = None       # index of the first file that could not be read: rows of the files before it, then the reference's OSError
         t_fetch = t_emit = 0.0
         while True:
             top_up()
@@ -701,21 +714,29 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
             t2 = time.perf_counter()
             blk = block_from_batch(b, res, syn, sfs_flat, args, paths, keys)
             kept.append(blk)
+            if blk.io_error is not None:
+                io_fail = blk.io_error if io_fail is None else min(io_fail, blk.io_error)
             if world == 1:
                 arrived[b.file_idx] = True
                 new_upto = upto + int(np.argmin(arrived[upto:]))        # first file that has not arrived yet
                 if new_upto > upto:
                     upto = new_upto
                     allb = RowBlock.concat(kept, args.cds).sorted()
-                    ready = allb.split_below(upto)
+                    ready = allb.split_below(upto if io_fail is None else min(upto, io_fail))
                     kept = [ready[1]]
                     emit_block(ready[0], sink, args, ing.table, paths, keys)
+                if io_fail is not None and upto >= io_fail:            # every file before the unreadable one has printed its rows
+                    sink.flush()
+                    sys.stdout.flush()
+                    raise_unreadable(paths[io_fail])
             t3 = time.perf_counter()
             tm["next_wait_s"] += t1 - t0
             t_fetch += t2 - t1
             t_emit += t3 - t2
             if trace is not None:
                 trace.append(("batch", t0 - t00, b.n_files, t1 - t0, t2 - t1, t3 - t2))
+        if io_fail is not None:          # (several ranks: the job dies with the error, as before; whoever launched the ranks ends the others)
+            raise_unreadable(paths[io_fail])
         if world > 1:
             # Every rank formats its own rows (natively, in parallel) as runs of consecutive files — a claim of the queue is
             # such a run — and rank 0 only puts the runs of all ranks in file order: its share of the work does not grow with

@@ -16,7 +16,7 @@ tests/golden/example_theta_0.01/ATTRIBUTION).
 Families: G1 examples, G2 synthetic grid, G3 odd symbols and
 FASTA syntax, G4 exhaustive codon-set tables, G5 coding alignments, G6
 populations, G7 command-line transcripts, G8 the BASELINE.json configurations at their full sizes, G9 sequences
-with non-ASCII characters, G10 units of hundreds to 2^20 rows.
+with non-ASCII characters, G10 units of hundreds to 2^20 rows, G11 a directory entry that cannot be read.
 """
 import contextlib
 import hashlib
@@ -631,7 +631,28 @@ def g10():
     dump("g10_many_rows.json", out)
 
 
+# ------------------------------------------------------- G11 a directory entry that cannot be read
+def g11():
+    """`--dir` over a directory that holds a subdirectory between two alignments: the reference prints the header and every row
+    before it, then dies at its open() (PolyFastA.py:104-108, :239) — stdout, the --out file, the exit code and the exception."""
+    ex = os.path.join(HERE, "example_theta_0.01")
+    tmp = tempfile.mkdtemp()
+    d = os.path.join(tmp, "mixed")
+    os.makedirs(os.path.join(d, "file2_is_a_directory"))
+    for fn in ("file1.fa", "file10.fa", "file3.fa"):
+        shutil.copyfile(os.path.join(ex, fn), os.path.join(d, fn))
+    out = {"layout": {"files": ["file1.fa", "file10.fa", "file3.fa"], "subdirectory": "file2_is_a_directory"}}
+    p = run_cli(["-d", d])
+    out["dir"] = {"args": ["-d", "{TMP}/mixed"], "stdout": p.stdout, "returncode": p.returncode, "stderr_tail": p.stderr.strip().splitlines()[-1].replace(tmp, "{TMP}")}
+    csv = os.path.join(tmp, "res.csv")
+    p = run_cli(["-d", d, "--cds", "--jc", "-o", csv, "-s"])
+    out["dir_cds_jc_out_silent"] = {"args": ["-d", "{TMP}/mixed", "--cds", "--jc", "-o", "{TMP}/res.csv", "-s"], "stdout": p.stdout, "file": open(csv).read(),
+                                    "returncode": p.returncode, "stderr_tail": p.stderr.strip().splitlines()[-1].replace(tmp, "{TMP}")}
+    shutil.rmtree(tmp)
+    dump("g11_unreadable_entry.json", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

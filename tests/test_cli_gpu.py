@@ -373,3 +373,26 @@ def test_directory_scale_every_row_every_column(gpu, tmp_path, monkeypatch):
         assert int(f[13]) >= 1
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_unreadable_directory_entry_dies_where_the_reference_dies(gpu, tmp_path):
+    """G11: a subdirectory between the alignments of `--dir`.  The reference prints the header and every row of the files
+    before it, then dies at its open() with IsADirectoryError, exit code 1 (PolyFastA.py:104-108, :239); rows of later files
+    never appear.  Same stdout, same --out file, same exit code, same exception — through the real command line."""
+    import subprocess
+    g = C.load("g11_unreadable_entry.json")
+    d = tmp_path / "mixed"
+    (d / g["layout"]["subdirectory"]).mkdir(parents=True)
+    for fn in g["layout"]["files"]:
+        shutil.copyfile(f"{C.GOLDEN}/example_theta_0.01/{fn}", d / fn)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for key in ("dir", "dir_cds_jc_out_silent"):
+        want = g[key]
+        argv = [a.replace("{TMP}", str(tmp_path)) for a in want["args"]]
+        p = subprocess.run([sys.executable, "-m", "polyfasta_amd"] + argv, cwd=root, capture_output=True, text=True, timeout=600)
+        assert p.returncode == want["returncode"] == 1, (p.returncode, p.stderr[-2000:])
+        assert p.stderr.strip().splitlines()[-1] == want["stderr_tail"].replace("{TMP}", str(tmp_path)), p.stderr[-2000:]
+        same_transcript(p.stdout, want["stdout"])
+        if "file" in want:
+            same_transcript(open(tmp_path / "res.csv").read(), want["file"])
+            os.unlink(tmp_path / "res.csv")
