@@ -106,6 +106,19 @@ __device__ inline uint32_t group_sum(uint32_t v, uint32_t lps_log) {
 // (s_waitcnt vmcnt(0)), i.e. for the tile that was just requested ahead of time.
 __device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// LDS atomic add (no return value) that the compiler does not order against the LDS-DMA in flight.  It cannot tell that these
+// bins and the tile buffer the DMA writes never overlap, so in front of every ds_add it emits it puts `s_waitcnt vmcnt(0)` — a
+// wait for the WHOLE tile a wavefront has just requested ahead of time: the coding pass's table work after the request, meant
+// to run under those loads, then ran behind them (round 4, read off the ISA).  Completion is ordered by the kernels' own
+// wave_lds_sync() (LDS operations of a wavefront complete in order).  PFA_LDS_ATOMIC_WAITS=1 (compile time): the builtin again.
+__device__ inline void lds_add_u32(uint32_t* p, uint32_t v) {
+#if defined(PFA_LDS_ATOMIC_WAITS) && PFA_LDS_ATOMIC_WAITS
+  atomicAdd(p, v);
+#else
+  asm volatile("ds_add_u32 %0, %1" ::"v"((uint32_t)(uintptr_t)(lptr_t)p), "v"(v) : "memory");
+#endif
+}
+
 // value of the previous lane (lane 0: 0): one DPP move instead of a ds_bpermute
 __device__ inline uint32_t wave_shr1(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);   // wave_shr:1
@@ -257,7 +270,7 @@ struct CodonPass {
   // with one codon are summed in a register, 2 .. kSynLdsBins + 1 in LDS, more (hardly ever) in memory
   __device__ void syn_add(uint32_t k, uint32_t t3) {
     if (k == 1u) acc_syn1 += t3;
-    else if (k - 2u < kSynLdsBins) atomicAdd(&synhist[k - 2u], t3);
+    else if (k - 2u < kSynLdsBins) lds_add_u32(&synhist[k - 2u], t3);
     else atomicAdd(replica(kernargs_again()->syn_num, rep_off) + (uint64_t)unit * PFA_SYN_BINS + k, t3);
   }
 

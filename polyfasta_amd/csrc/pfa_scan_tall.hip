@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(64) scan_tall_kernel(const ScanArgs A) {
     const uint32_t hi1 = umax(cA, cC), lo1 = umin(cA, cC), hi2 = umax(cG, cT), lo2 = umin(cG, cT);
     const uint32_t second = umax(umin(hi1, hi2), umax(lo1, lo2));
     if (second == 0u) acc_bad += 1u;
-    else if (second - 1u < HB) atomicAdd(&hist[second - 1u], 1u);
+    else if (second - 1u < HB) atomicAdd(&hist[second - 1u], 1u);   // (lds_add_u32, pfa_kernels.h, measured here: equal within the spread)
     else {
       const kernarg_ptr_t K = kernargs_again();
       atomicAdd(replica(K->sfs, (blockIdx.y & K->rep_mask) * K->rep_stride) + D.sfs_off + second - 1u, 1u);

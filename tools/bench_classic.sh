@@ -10,7 +10,7 @@ one() {
   local label=$1; shift
   for lib in "" $OTHER; do
     line=$(PFA_LIB=$lib python3 $R/bench.py --no-cpu-baseline --no-extras --steps 24 --warmup 3 "$@" 2>>$OUT.err)
-    echo "$label ${lib:+[$(basename $lib)]} :: $(echo "$line" | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print("%.0f GB/s  frac %.3f  kernel %.3f ms (min %.3f)  %s" % (j["roofline"]["achieved"], j["roofline"]["frac"], j["roofline"]["kernel_ms_avg"], j["timing_ms"]["kernel_ms_min"], j["roofline"]["kernel"][:60]))')" >> $OUT
+    echo "$label ${lib:+[$(basename $lib)]} :: $(echo "$line" | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print("%.0f GB/s  frac %.3f  kernel %.3f ms (min %.3f)  %s" % (j["roofline"]["achieved"], j["roofline"]["frac"], j["roofline"]["kernel_ms_avg"], j["timing_ms"]["kernel_min"], j["roofline"]["kernel"][:60]))')" >> $OUT
   done
 }
 # the first seconds of a box run at higher clocks (the first measurement of a call reads 2 % high): spend them on a discarded run

@@ -1,9 +1,12 @@
 // Host micro-benchmark: how fast can T threads get the bytes of many page-cached files in front of a parser — read() into a
 // thread-local buffer against mmap(PROT_READ, MAP_POPULATE) + munmap — each followed by one pass over the bytes (memchr for '\n',
-// what the indexer does).  usage: read_vs_mmap DIR n_files file_bytes threads   (writes the files first if DIR is empty)
+// what the indexer does).  usage: read_vs_mmap DIR n_files file_bytes threads [processes]   (writes the files first if DIR is empty)
+// With `processes` P > 1 every (mode, repeat) is run by P forked processes of `threads` threads each, process p taking the files
+// i = p (mod P): P address spaces, as P ranks of a multi-GPU job have (the mmap / munmap / page-fault paths take a per-process lock).
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -23,6 +26,7 @@ int main(int argc, char** argv) {
   const int n = atoi(argv[2]);
   const size_t fb = (size_t)atoll(argv[3]);
   const int T = atoi(argv[4]);
+  const int P = argc > 5 ? atoi(argv[5]) : 1;
   mkdir(dir.c_str(), 0755);
   std::vector<std::string> paths(n);
   std::vector<char> line(fb, 'A');
@@ -40,13 +44,30 @@ int main(int argc, char** argv) {
       std::atomic<int> next{0};
       std::atomic<uint64_t> lines{0};
       const double t0 = now();
+      int me = 0;
+      std::vector<pid_t> kids;
+      if (P > 1) {
+        for (me = 0; me < P; ++me) {
+          const pid_t k = fork();
+          if (k == 0) break;
+          kids.push_back(k);
+        }
+        if (me == P) {    // the parent: wait for the P workers
+          for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); }
+          const double dt = now() - t0;
+          printf("%-22s procs %2d x threads %3d  %8.0f files/s  %7.1f GB/s\n", mode == 0 ? "read()" : mode == 1 ? "mmap MAP_POPULATE" : "mmap, faults on touch", P, T,
+                 n / dt, n * (double)fb / dt / 1e9);
+          fflush(stdout);
+          continue;
+        }
+      }
       std::vector<std::thread> th;
       for (int t = 0; t < T; ++t)
         th.emplace_back([&]() {
           std::vector<char> buf(fb + 64);
           uint64_t nl = 0;
           for (;;) {
-            const int i = next.fetch_add(1);
+            const int i = next.fetch_add(1) * P + me;
             if (i >= n) break;
             const int fd = open(paths[i].c_str(), O_RDONLY);
             if (fd < 0) continue;
@@ -68,6 +89,7 @@ int main(int argc, char** argv) {
           lines += nl;
         });
       for (auto& x : th) x.join();
+      if (P > 1) _exit(0);
       const double dt = now() - t0;
       printf("%-22s threads %3d  %8.0f files/s  %7.1f GB/s  (lines %llu)\n", mode == 0 ? "read()" : mode == 1 ? "mmap MAP_POPULATE" : "mmap, faults on touch", T,
              n / dt, n * (double)fb / dt / 1e9, (unsigned long long)lines.load());
