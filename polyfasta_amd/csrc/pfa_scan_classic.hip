@@ -243,9 +243,10 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
 #endif
 
     // ---------------- tier 2: exact allele counts of the variable sites
-    // LPS = 4 lanes per site walk its column (8 or 16 lanes for tiles with few variable sites were
-    // measured: no gain, the walk is bound by LDS bank conflicts — every row of a column sits in the
-    // same bank).  Fast path: x = the byte of row 0, y = x ^ (XOR byte of the
+    // LPS lanes per site walk its column: 4, or 8 in 128-site tiles with at most 8 variable sites (below).  Every row of a column
+    // sits in the same LDS bank (rows are 128 or 256 bytes apart), but those conflicts are NOT what bounds the walk: with every
+    // intra-group conflict removed the shapes gain 0-2.5 % (profiles/r03_lds_bank_conflict_ablation.txt), and no single stage of
+    // tier 2 carries its cost (profiles/r04_classic_stage_ablation.txt).  Fast path: x = the byte of row 0, y = x ^ (XOR byte of the
     // site); when every row holds x or y the site has exactly these two alleles (2 compares per
     // byte).  Otherwise (3+ alleles, ~1 % of variable sites) the column is walked again with six
     // counters, and any byte outside A C G T - N takes the exact generic path.
