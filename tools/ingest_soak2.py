@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised soak of the files -> rows path: directories of mixed files (clean A/C/G/T of every length modulo 64, lower case,
 other symbols, wrapped lines, CR / CRLF, unequal lengths, non-ASCII sequence characters), random loader threads and slot sizes;
-every row against the oracle (its reader on the same text, then the C scan).  usage: tools/ingest_soak2.py [seconds]"""
+a random mode per directory (plain, --cds --jc, -p, -p --cds with a key nobody carries); EVERY COLUMN of every row and every
+comment line against the checker (the oracle's reader on the same text, the C scan, the oracle's own finishing math).
+usage: tools/ingest_soak2.py [seconds]"""
 import io, os, sys, tempfile, shutil, time
 from contextlib import redirect_stdout
 import numpy as np
@@ -9,6 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from polyfasta_amd import cli, fasta  # noqa: E402
 from oracle import c_oracle, polyfasta_oracle as orc  # noqa: E402
+from tests import _cases as C  # noqa: E402
+
+MODES = ([], ["--cds", "--jc"], ["-p", "pop1,pop2"], ["-p", "pop2,nopop,pop1", "--cds"])
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t_end = time.time() + budget
@@ -19,6 +24,9 @@ while time.time() < t_end:
     rng = np.random.default_rng(seed)
     d = tempfile.mkdtemp(prefix="pfa_soak2_", dir="/dev/shm")
     want = {}
+    flags = MODES[seed % len(MODES)]
+    cds, jc = "--cds" in flags, "--jc" in flags
+    keys = flags[flags.index("-p") + 1].split(",") if "-p" in flags else None
     try:
         for i in range(int(rng.integers(3, 60))):
             n = int(rng.choice([2, 3, 7, 12, 50, 65, 130]))
@@ -57,27 +65,36 @@ while time.time() < t_end:
                 fh.write(text)
             dd = orc.parse_fasta_lines(io.StringIO(text, newline=None))
             if len({len(v) for v in dd.values()}) != 1:
-                want[name] = None
+                want[name] = [f"# Sequences do not have the same length: {name}"]
             else:
-                o = c_oracle.scan(fasta.matrix_from_dict(dd))
-                want[name] = (len(next(iter(dd.values()))), len(dd), o["S"])
+                m = fasta.matrix_from_dict(dd)
+                Lc = m.shape[1]
+                lines_ = [f"# CDS sequence length is not a multiple of 3: {name}"] if cds and Lc % 3 else []      # PolyFastA.py:114-119
+                for key in keys or [None]:
+                    sub = None if key is None else [r for r, h in enumerate(dd) if key in h]                        # :125
+                    if sub is not None and not sub:
+                        lines_.append(f"# Pop {key} string was not found in fasta headers.")                        # :126-131
+                        continue
+                    o = c_oracle.scan(m, rows=sub, cds=cds)
+                    lines_.append(orc.row_from_counts(name, key or "NA", len(dd) if sub is None else len(sub), Lc, o, cds, jc))
+                want[name] = lines_
         os.environ["PFA_THREADS"] = str(int(rng.choice([1, 3, 8, 16, 24])))
         os.environ["PFA_INGEST_SLOT_BYTES"] = str(int(rng.choice([1 << 16, 1 << 20, 1 << 24])))
         buf = io.StringIO()
         with redirect_stdout(buf):
-            cli.main(["-d", d, "-s"])
+            cli.main(["-d", d, "-s"] + flags)
         lines = buf.getvalue().splitlines()
-        assert len(lines) == len(want), (seed, len(lines), len(want))
-        for ln, name in zip(lines, sorted(want)):
-            if want[name] is None:
-                assert ln == f"# Sequences do not have the same length: {name}", (seed, ln)
-            else:
-                f = ln.split(",")
-                assert f[0] == name and (int(f[1]), int(f[3]), int(f[4])) == want[name], (seed, ln, want[name])
-                rows_checked += 1
+        expect = [ln for name in sorted(want) for ln in want[name]]
+        assert len(lines) == len(expect), (seed, flags, len(lines), len(expect))
+        for ln, w in zip(lines, expect):
+            if ln == w:
+                rows_checked += not w.startswith("#")
+                continue
+            assert not w.startswith("#") and C.row_matches(ln, w, cds, jc) is None, (seed, flags, ln, w, C.row_matches(ln, w, cds, jc))
+            rows_checked += 1
         files_checked += len(want)
     finally:
         shutil.rmtree(d, ignore_errors=True)
     if seed % 20 == 0:
         print(f"seed {seed}: {files_checked} files, {rows_checked} rows identical", flush=True)
-print(f"ingest soak: {files_checked} files over {seed} directories, {rows_checked} rows identical to the oracle")
+print(f"ingest soak: {files_checked} files over {seed} directories in four modes, {rows_checked} rows identical to the checker in every column")
