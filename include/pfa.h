@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 4
+#define PFA_ABI_VERSION 5
 
 /* error codes */
 #define PFA_OK 0

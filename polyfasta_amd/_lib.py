@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PFA_LIB") or os.path.join(_HERE, "libpfa_hip.so")   # PFA_LIB: timing experiments with other builds
 
-PFA_ABI_VERSION = 4
+PFA_ABI_VERSION = 5
 PFA_NO_ROW_IDX = 0xFFFFFFFF
 PFA_FLAG_CDS = 1
 PFA_WANT_VAR_BITMAP = 1
