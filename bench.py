@@ -29,7 +29,11 @@ import os
 import sys
 import time
 
-import numpy as np
+# (numpy's import starts one spinning OpenBLAS thread per CPU the machine shows: 2 CPU-seconds on a 256-CPU box with a quota of 16;
+# nothing here uses BLAS — polyfasta_amd/__main__.py does the same for the command line)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

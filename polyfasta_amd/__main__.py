@@ -4,6 +4,14 @@ import time
 
 _t_enter = time.time()          # wall clock: bench.py's cold_start leg subtracts its own spawn time
 
+# numpy's import starts one OpenBLAS thread per CPU the machine SHOWS, and they spin for a while: 256 threads and 1.7-2.3 CPU-seconds on
+# a GPU box whose control group grants 16 CPUs — the whole quota of a scheduler period gone before the first file is read (the group
+# is then frozen until the period ends: ~100 ms at some random later point, usually the exit), and 50 ms of import time.  Nothing
+# here uses BLAS (profiles/r04_startup_cpu_cost.txt).  A value the user exported is kept.
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+os.environ.setdefault("MKL_NUM_THREADS", "1")
+
 
 def _launcher_only(argv):
     """`--gpus N` with N > 1 and no launcher's environment: this process only starts the ranks (dist.spawn_ranks) and
@@ -60,6 +68,11 @@ finally:
             pass
 # every row has been written: leave without the interpreter's and the HIP runtime's teardown (45 ms of a
 # 0.3 s one-file run); the driver releases the device when the process is gone
+if os.environ.get("PFA_EXIT") == "shutdown":      # timing experiment: the library's own teardown first (buffers freed, stream destroyed)
+    _t = time.time()
+    from . import _lib as _l
+    _l.shutdown()
+    print(f"PFA_EXIT shutdown {1e3 * (time.time() - _t):.1f} ms", file=sys.stderr)
 sys.stdout.flush()
 sys.stderr.flush()
 os._exit(rc or 0)
