@@ -68,11 +68,14 @@ finally:
             pass
 # every row has been written: leave without the interpreter's and the HIP runtime's teardown (45 ms of a
 # 0.3 s one-file run); the driver releases the device when the process is gone
-if os.environ.get("PFA_EXIT") == "shutdown":      # timing experiment: the library's own teardown first (buffers freed, stream destroyed)
+if os.environ.get("PFA_EXIT") in ("shutdown", "reset"):      # timing experiments: the library's own teardown first (buffers freed, stream destroyed), + hipDeviceReset
     _t = time.time()
     from . import _lib as _l
     _l.shutdown()
-    print(f"PFA_EXIT shutdown {1e3 * (time.time() - _t):.1f} ms", file=sys.stderr)
+    if os.environ["PFA_EXIT"] == "reset":
+        import ctypes as _c
+        _c.CDLL("libamdhip64.so").hipDeviceReset()
+    print(f"PFA_EXIT {os.environ['PFA_EXIT']} {1e3 * (time.time() - _t):.1f} ms", file=sys.stderr)
 sys.stdout.flush()
 sys.stderr.flush()
 os._exit(rc or 0)
