@@ -76,6 +76,18 @@ if os.environ.get("PFA_EXIT") in ("shutdown", "reset"):      # timing experiment
         import ctypes as _c
         _c.CDLL("libamdhip64.so").hipDeviceReset()
     print(f"PFA_EXIT {os.environ['PFA_EXIT']} {1e3 * (time.time() - _t):.1f} ms", file=sys.stderr)
+# The kernel's teardown of the process's GPU context (after the last instruction here) takes 2 ms or 60-100 ms: it waits for
+# something that completes sooner when other CPUs pass through the scheduler at that moment — a process that dies with a few
+# dozen sleeping threads (numpy's 256 idle OpenBLAS threads did it by accident) exits fast, a single-threaded one slowly.
+# Measured from a shell, one file, three alternating rounds (profiles/r04_shell_cold_start_ab.txt): one OpenBLAS thread
+# 217-359 ms (median 287), 256 threads 159-334 (median 230), one thread + 16-64 sleeping threads at exit 121-293 (median 165).
+# PFA_EXIT_KICK=0 switches it off.
+_kick = int(os.environ.get("PFA_EXIT_KICK", "32") or 0)
+if _kick > 0:
+    import threading
+    _ev = threading.Event()
+    for _ in range(_kick):
+        threading.Thread(target=_ev.wait, daemon=True).start()
 sys.stdout.flush()
 sys.stderr.flush()
 os._exit(rc or 0)
