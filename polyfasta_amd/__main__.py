@@ -84,10 +84,13 @@ if os.environ.get("PFA_EXIT") in ("shutdown", "reset"):      # timing experiment
 # PFA_EXIT_KICK=0 switches it off.
 _kick = int(os.environ.get("PFA_EXIT_KICK", "32") or 0)
 if _kick > 0:
-    import threading
-    _ev = threading.Event()
-    for _ in range(_kick):
-        threading.Thread(target=_ev.wait, daemon=True).start()
+    try:
+        import threading
+        _ev = threading.Event()
+        for _ in range(_kick):
+            threading.Thread(target=_ev.wait, daemon=True).start()
+    except Exception:           # noqa: BLE001  (a thread limit: the exit is only slower)
+        pass
 sys.stdout.flush()
 sys.stderr.flush()
 os._exit(rc or 0)
