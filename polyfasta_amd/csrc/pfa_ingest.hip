@@ -149,6 +149,7 @@ constexpr size_t kMinSlot = size_t(256) << 10;
 constexpr size_t kRampSlot = size_t(2) << 20;
 constexpr uint32_t kDefaultSlots = 8;
 constexpr size_t kMaxBatchBytes = size_t(128) << 20;
+constexpr unsigned long long kDirectMaxText = 256ull << 20;   // direct mode: most text (bytes of the files) of a job read in place by the card
 constexpr uint64_t kRowPacked = 1ull << 63;   // FileRec::row_off: the row travels two bits per base
 inline size_t up16(size_t x) { return (x + 15u) & ~size_t(15); }
 constexpr int kBatchEvents = 64;
@@ -356,21 +357,28 @@ int new_use(pfa_ingest* g, std::unique_lock<std::mutex>& lk, size_t need, uint32
     if (!ok) { (void)hipGetLastError(); give_pinned(p); fail(g, PFA_ERR_NOMEM, "ingest: cannot allocate buffers for a " + std::to_string(need) + "-byte file"); return -1; }
     u.h = p.h; u.cap = p.cap; u.d = d;
   } else {
-    const int hs = (int)(g->ring_seq % g->n_slots);
-    const int ds = (int)(g->ring_seq % g->n_dev_slots);
+    // direct mode (small jobs: the card reads the pinned buffers itself, nothing is recycled): the "ring" grows by one buffer per
+    // use, each as large as the use may get
+    if (g->direct && g->ring_seq >= g->slots.size()) {
+      g->slots.resize((size_t)g->ring_seq + 1u);
+      g->slot_user.resize((size_t)g->ring_seq + 1u, -1);
+    }
+    const int hs = g->direct ? (int)g->ring_seq : (int)(g->ring_seq % g->n_slots);
+    const int ds = g->direct ? 0 : (int)(g->ring_seq % g->n_dev_slots);
     g->ring_seq += 1;
     while (!g->stop && g->slot_user[(size_t)hs] >= 0) g->cv_slot.wait(lk);   // its last copy is still in flight
     if (g->stop) return -1;
+    // the first slots are closed early (2, 4, 8 ... MiB): the link starts on the first few files, not on the first 64 MiB
+    u.cap = std::min(g->slot_bytes, std::max(need, kRampSlot << std::min<uint64_t>(g->ring_seq - 1, 8)));
     if (!g->slots[(size_t)hs].h) {
+      const size_t want = g->direct ? u.cap : g->slot_bytes;
       lk.unlock();
-      Pinned p = take_pinned(g->slot_bytes);
+      Pinned p = take_pinned(want);
       lk.lock();
       if (!p.h) { fail(g, PFA_ERR_NOMEM, "ingest: cannot allocate a pinned slot"); return -1; }
       g->slots[(size_t)hs] = p;
     }
     u.h = g->slots[(size_t)hs].h;
-    // the first slots are closed early (8, 16, 32 MiB): the link starts on the first few files, not on the first 64 MiB
-    u.cap = std::min(g->slot_bytes, std::max(need, kRampSlot << std::min<uint64_t>(g->ring_seq - 1, 8)));
     u.host_slot = hs;
     u.dev_slot = ds;
     if (g->direct) {
@@ -838,7 +846,25 @@ int pfa_ingest_feed(pfa_ingest* g, const uint32_t* file_idx, uint32_t n, int las
     if (last) g->feed_closed = true;
     if (!g->threads_started && (!g->feed.empty() || g->feed_closed)) {
       g->threads_started = true;
-      g->direct = g->feed_closed && g->feed.size() <= std::min<size_t>(4, g->n_slots) && !getenv("PFA_INGEST_NO_DIRECT");   // (slots are never recycled in this mode)
+      // Direct mode: a job that is small — a handful of files, or (round 4) up to 4 096 files holding at most kDirectMaxText bytes
+      // (stat() of each, PFA_INGEST_DIRECT_MAX overrides) — and fed in one piece pays neither the copy stream's queue (20 ms) nor the
+      // copy engine's set-up (9 ms) nor the device text ring: repack_kernel reads the pinned buffers over PCIe (a fresh process,
+      // 8-64 files: files -> rows 21-30 ms with the copy pipeline).  Nothing is recycled in this mode: the pinned "ring" grows by
+      // one buffer per use (new_use), bounded by the text the job holds.
+      auto small_job = [&]() -> bool {
+        if (g->feed.size() <= std::min<size_t>(4, g->n_slots)) return true;
+        unsigned long long cap = pfa::kDirectMaxText;
+        if (const char* e = getenv("PFA_INGEST_DIRECT_MAX")) cap = strtoull(e, nullptr, 10);
+        if (cap == 0 || g->feed.size() > 4096) return false;
+        unsigned long long total = 0;
+        for (const uint32_t f : g->feed) {
+          struct stat sb;
+          if (stat(g->paths[f].c_str(), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) total += (unsigned long long)sb.st_size;
+          if (total > cap) return false;
+        }
+        return true;
+      };
+      g->direct = g->feed_closed && !getenv("PFA_INGEST_NO_DIRECT") && small_job();
       const uint32_t nt = std::max(1u, std::min<uint32_t>(g->want_threads, (uint32_t)std::max<size_t>(g->feed.size(), 1)));
       g->want_threads = nt;
       for (uint32_t t = 0; t < nt; ++t) g->workers.emplace_back(pfa::worker, g);

@@ -138,14 +138,22 @@ def test_many_files_small_buffers(gpu, tmp_path, monkeypatch):
         (tmp_path / f"f{i:02d}.fa").write_text(synth.to_fasta_text(synth.headers_for(12), m))
         o = c_oracle.scan(m)
         rows[f"f{i:02d}.fa"] = (L, o["S"])
-    for threads in ("1", "3", "16"):
-        monkeypatch.setenv("PFA_THREADS", threads)
-        rc, out = run_cli(["-d", str(tmp_path), "-s"])
-        lines = out.rstrip("\n").split("\n")
-        assert [ln.split(",")[0] for ln in lines] == sorted(rows)
-        for ln in lines:
-            f = ln.split(",")
-            assert (int(f[1]), int(f[4])) == rows[f[0]]
+    # the copy pipeline (PFA_INGEST_DIRECT_MAX=0: pinned ring, uploader, device text ring) and the direct mode of small jobs
+    # (the card reads the pinned buffers itself; one buffer per use, nothing recycled)
+    for direct_max in ("0", None):
+        if direct_max is None:
+            monkeypatch.delenv("PFA_INGEST_DIRECT_MAX", raising=False)
+        else:
+            monkeypatch.setenv("PFA_INGEST_DIRECT_MAX", direct_max)
+        for threads in ("1", "3", "16"):
+            monkeypatch.setenv("PFA_THREADS", threads)
+            rc, out = run_cli(["-d", str(tmp_path), "-s"])
+            lines = out.rstrip("\n").split("\n")
+            assert [ln.split(",")[0] for ln in lines] == sorted(rows)
+            for ln in lines:
+                f = ln.split(",")
+                assert (int(f[1]), int(f[4])) == rows[f[0]]
+            assert (cli.last_stats["bytes_copied"] == 0) == (direct_max is None), cli.last_stats     # direct: no H2D copy at all
 
 
 def test_ingest_repacks_any_text_like_the_reference_reader(gpu, tmp_path):
@@ -206,6 +214,7 @@ def test_ingest_soak_mixed_directory(gpu, tmp_path, monkeypatch):
     from oracle import c_oracle
     import numpy as np
     monkeypatch.setenv("PFA_INGEST_SLOT_BYTES", str(3 << 20))
+    monkeypatch.setenv("PFA_INGEST_DIRECT_MAX", "0")      # the copy pipeline (pinned ring, uploader), not the direct mode of small jobs
     from oracle import polyfasta_oracle as orc
     rng = np.random.default_rng(5)
     want = []

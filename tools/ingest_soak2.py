@@ -80,6 +80,11 @@ while time.time() < t_end:
                 want[name] = lines_
         os.environ["PFA_THREADS"] = str(int(rng.choice([1, 3, 8, 16, 24])))
         os.environ["PFA_INGEST_SLOT_BYTES"] = str(int(rng.choice([1 << 16, 1 << 20, 1 << 24])))
+        # half the directories through the copy pipeline (pinned ring, uploader, device text ring), half in the direct mode of small jobs
+        if seed % 2:
+            os.environ["PFA_INGEST_DIRECT_MAX"] = "0"
+        else:
+            os.environ.pop("PFA_INGEST_DIRECT_MAX", None)
         buf = io.StringIO()
         with redirect_stdout(buf):
             cli.main(["-d", d, "-s"] + flags)
