@@ -10,9 +10,10 @@ from polyfasta_amd import _lib, scan, stats
 from tests import test_gpu_random as T
 _lib.init(0)
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+first_seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 t0 = time.time()
 units_checked = 0
-for seed in range(1000, 1000 + n_seeds):
+for seed in range(first_seed, first_seed + n_seeds):
     rng = np.random.default_rng(seed)
     lean = seed % 2 == 0
     # every tile width in turn (unset: the plan's own choice, which for these small batches is narrow tiles)
