@@ -314,17 +314,15 @@ struct CodonPass {
     }
 #pragma unroll
     for (uint32_t it = 0; it < NIT; ++it) {
-      bool joint = false;
-      if (endo[it] >= 0) {
-        const uint32_t dv = dw[it];
-        const bool v0 = (dv & 0xFFu) != 0u, v1 = (dv & 0xFF00u) != 0u, v2 = (dv & 0xFF0000u) != 0u;
-        const uint32_t nvar = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
-        joint = nvar >= 2u;                                // rare: the codons must be read row by row
-        single[it] = nvar == 1u;                           // one variable position: resolved from its allele mask
-        mono[it] = nvar == 0u;
-        pv[it] = v0 ? 0u : v1 ? 1u : 2u;
-      }
-      mjoint[it] = __ballot(joint);
+      // (branch-free: predicated selects instead of an exec-masked block per candidate column)
+      const bool has = endo[it] >= 0;
+      const uint32_t dv = dw[it];
+      const bool v0 = (dv & 0xFFu) != 0u, v1 = (dv & 0xFF00u) != 0u, v2 = (dv & 0xFF0000u) != 0u;
+      const uint32_t nvar = (uint32_t)v0 + (uint32_t)v1 + (uint32_t)v2;
+      single[it] = has && nvar == 1u;                      // one variable position: resolved from its allele mask
+      mono[it] = has && nvar == 0u;
+      pv[it] = v0 ? 0u : v1 ? 1u : 2u;
+      mjoint[it] = __ballot(has && nvar >= 2u);            // rare: the codons must be read row by row
     }
   }
 
@@ -416,14 +414,10 @@ struct CodonPass {
       // 2-bit codes at bits 1, 9, 17 of t2 -> 16 c0 + 4 c1 + c2: one 24-bit multiply lines them up at bits 17..22
       cidx_[it] = (__umul24(t2, 0x100401u) >> 17) & 0x3Fu;
       const uint32_t ci = lane_lookup(cidx_[it], my_cinfo);
-      if (mono[it]) {
-        if (bad_[it] == 0u) {
-          acc_syn1 += ci & 7u;
-          acc_stops += ci >> 7;
-        } else {
-          acc_missing += 1u;
-        }
-      }
+      const bool clean = mono[it] && bad_[it] == 0u;       // (predicated adds: no exec-masked blocks)
+      acc_syn1 += clean ? (ci & 7u) : 0u;
+      acc_stops += clean ? (ci >> 7) : 0u;
+      acc_missing += (mono[it] && bad_[it] != 0u) ? 1u : 0u;
     }
     // One variable position, on the lane that owns the column: the codon set is the consensus
     // codon with every A/C/G/T allele of that position substituted (rows with another symbol
@@ -443,15 +437,16 @@ struct CodonPass {
       const uint32_t j = b4 * 16u + (am & 15u);             // entry of plane p
       const uint32_t w0 = lane_lookup(j >> 2, my_slut[0]), w1 = lane_lookup(j >> 2, my_slut[1]), w2 = lane_lookup(j >> 2, my_slut[2]);
       const uint32_t v = ((p == 0u ? w0 : p == 1u ? w1 : w2) >> (8u * (j & 3u))) & 0xFFu;
-      if (!valid) return;
-      if (k == 0u) { acc_missing += 1u; return; }
-      const uint32_t t3 = v & 0x1Fu;
-      syn_add(k, t3);
-      acc_stops += (v >> 5) & 1u;
-      const bool is_s = (v & 0x40u) != 0u, is_n = (v & 0x80u) != 0u;
+      const bool live = valid && k != 0u;
+      acc_missing += (valid && k == 0u) ? 1u : 0u;
+      if (live) syn_add(k, v & 0x1Fu);
+      acc_stops += live ? (v >> 5) & 1u : 0u;
+      const bool is_s = live && (v & 0x40u) != 0u, is_n = live && (v & 0x80u) != 0u;
       const auto hs = hv.h;
-      if (is_s) { acc_segS += 1u; acc_HS += hs; }
-      if (is_n) { acc_segN += 1u; acc_HN += hs; }
+      acc_segS += is_s ? 1u : 0u;
+      acc_HS += is_s ? hs : 0;
+      acc_segN += is_n ? 1u : 0u;
+      acc_HN += is_n ? hs : 0;
       if (BITMAPS && (is_s || is_n) && syn_bm != nullptr) mark_site(is_s, rel + (int)p);
     };
     if constexpr (SPLIT) {
