@@ -735,8 +735,9 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
             t_emit += t3 - t2
             if trace is not None:
                 trace.append(("batch", t0 - t00, b.n_files, t1 - t0, t2 - t1, t3 - t2))
-        if io_fail is not None:          # (several ranks: the job dies with the error, as before; whoever launched the ranks ends the others)
+        if world == 1 and io_fail is not None:
             raise_unreadable(paths[io_fail])
+        fail_at = None       # several ranks: the first unreadable file of ALL ranks (every rank takes part in the exchange below)
         if world > 1:
             # Every rank formats its own rows (natively, in parallel) as runs of consecutive files — a claim of the queue is
             # such a run — and rank 0 only puts the runs of all ranks in file order: its share of the work does not grow with
@@ -747,9 +748,18 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
             mine = RowBlock.concat(kept, args.cds).sorted()
             runs = text_runs(mine, ing.table, args) if (not mine.specials and not args.sfs and sink.bulk_ok()) else None
             tg1 = time.perf_counter()
-            flags = comm.all_gather_fixed(np.array([runs is not None], dtype=np.uint8))     # (also where a rank waits for the slowest one)
+            # one exchange: "my rows are plain text runs" and the index of my first unreadable file (-1: none)
+            mine_flags = np.array([int(runs is not None), -1 if io_fail is None else int(io_fail)], dtype=np.int64)
+            flags = comm.all_gather_fixed(mine_flags.view(np.uint8)).view(np.int64).reshape(-1, 2)     # (also where a rank waits for the slowest one)
             tg2 = time.perf_counter()
-            if bool(flags.all()):
+            bad = flags[:, 1][flags[:, 1] >= 0]
+            if len(bad):
+                # The reference prints every row before the unreadable file and dies at its open() (PolyFastA.py:104-108, :239): the rows
+                # below it travel to rank 0 as blocks, rank 0 writes them and raises the error; the other ranks leave with its exit code.
+                fail_at = int(bad.min())
+                mine = mine.split_below(fail_at)[0]
+                runs = None
+            if fail_at is None and bool(flags[:, 0].all()):
                 blob = pickle.dumps(runs, protocol=pickle.HIGHEST_PROTOCOL)
                 tg3 = time.perf_counter()
                 parts = comm.gather_bytes(blob, dst=0)
@@ -771,6 +781,14 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
                       root_merge_write_s=tg5 - tg4)
         if trace is not None:
             trace.append(("loop_end", time.perf_counter() - t00))
+        if fail_at is not None:
+            sink.flush()
+            sys.stdout.flush()
+            if comm is not None:
+                comm.barrier()
+            if rank == 0:
+                raise_unreadable(paths[fail_at])
+            raise SystemExit(1)
         tb = time.perf_counter()
         if comm is not None:
             comm.barrier()

@@ -14,10 +14,12 @@ from polyfasta_amd import cli  # noqa: E402
 from tests._gloo_comm import GlooComm  # noqa: E402
 
 buf = io.StringIO()
-with redirect_stdout(buf):
-    rc = cli.main(sys.argv[2:], comm=GlooComm())
-if os.environ.get("RANK", "0") == "0":
-    open(sys.argv[1], "w").write(buf.getvalue())
-else:
-    assert buf.getvalue() == "", "only rank 0 prints"
+try:
+    with redirect_stdout(buf):
+        rc = cli.main(sys.argv[2:], comm=GlooComm())
+finally:      # (also when the job dies where the reference dies: what rank 0 printed until then)
+    if os.environ.get("RANK", "0") == "0":
+        open(sys.argv[1], "w").write(buf.getvalue())
+    else:
+        assert buf.getvalue() == "", "only rank 0 prints"
 sys.exit(rc)

@@ -104,6 +104,33 @@ def test_two_rank_cli_writes_the_out_file_like_one_process(gpu, tmp_path):
     assert got_stdout == want_stdout.replace(str(one), str(two)) and want_stdout.endswith("\n") and "\r Writting to" in got_stdout
 
 
+@pytest.mark.parametrize("extra", [[], ["--cds", "-p", "pop1,pop2"]])
+def test_two_rank_cli_dies_at_an_unreadable_entry_like_one_process(gpu, tmp_path, extra):
+    """A subdirectory among the files of `--dir`, two ranks: rank 0 prints every row of the files before it — whichever rank
+    scanned them — and dies with the reference's error (PolyFastA.py:104-108, :239: IsADirectoryError, exit code 1); the
+    other rank leaves with the same code; rows of later files never appear.  Byte for byte the single process's output."""
+    d = _make_dir(tmp_path, n_files=31, odd=False)
+    (d / "g17_is_a_directory").mkdir()
+    argv = ["-d", str(d), "-s"] + extra
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        with pytest.raises(IsADirectoryError):
+            cli.main(argv)
+    want = buf.getvalue()
+    assert 17 <= want.count("\n") <= 2 * 18 and "g18.fa" not in want and "g16.fa" in want
+    out = tmp_path / "rank0.csv"
+    port = dist._free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_cli_rank_worker.py"), str(out)] + argv,
+                                      env=env, cwd=ROOT, stderr=subprocess.PIPE))
+    errs = [p.communicate(timeout=600)[1].decode() for p in procs]
+    assert [p.returncode for p in procs] == [1, 1], errs
+    assert "IsADirectoryError" in errs[0] and "g17_is_a_directory" in errs[0] and "IsADirectoryError" not in errs[1]
+    assert open(out).read() == want
+
+
 def test_rccl_comm_one_rank(gpu, tmp_path):
     """pfa_comm_* on librccl with a world of one: unique id through the rendezvous file, barrier,
     max-reduction, host-staged all-gather, and the device-side gather of a plan's records."""
