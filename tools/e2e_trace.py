@@ -5,8 +5,11 @@ from contextlib import redirect_stdout
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from polyfasta_amd import _lib, cli, dist, synth  # noqa: E402
-if os.environ.get("PFA_BIND"):
-    print("bound to", dist.bind_to_gpu_node(0, 1), flush=True)
+# The files are written by this thread: bind it to the CPUs next to the GPU FIRST (as bench.py does), or the tmpfs pages land on whichever
+# socket the scheduler picked and every run of this process reads them across the socket link — 143 k instead of 220 k alignments/s, in about
+# half of the processes (round 4: the "slow mode" of a whole process).  PFA_NO_BIND=1: leave it to chance.
+if not os.environ.get("PFA_NO_BIND"):
+    print("bound to", len(dist.bind_to_gpu_node(0, 1) or []), "CPUs", flush=True)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 extra = sys.argv[2:]
 N, L = 50, 10000
