@@ -520,6 +520,8 @@ static void finish_bucket(Bucket& b, const BucketKey& k, bool bitmaps, const pfa
     // register tiles (timing experiment until measured: PFA_REG_TILES=1): lean instantiations only
     if (env_u32("PFA_REG_TILES", 0u) && !b.cfg.mapped && !bitmaps) b.cfg.nir = classic_reg_tile_class(k.tw, b.n_max);
   }
+  // (timing experiments: LDS a wavefront does not use, i.e. fewer wavefronts per CU with everything else equal)
+  if (getenv("PFA_LDS_PAD")) b.cfg.lds_bytes = std::min(kLdsPerCu, b.cfg.lds_bytes + env_u32("PFA_LDS_PAD", 0u));
   // chunking: enough single-wave workgroups to fill 256 CUs several times over, but whole
   // alignments per wave once the batch is large (fewer atomics).  96 single-wave workgroups per
   // CU measured best for the bench workload (10 tiles per chunk: 6.48 TB/s; 20 tiles 6.36,

@@ -52,13 +52,13 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   constexpr uint32_t TW = G::TW;
 
   const uint32_t lane = threadIdx.x;
-  const uint32_t unit = A.unit_ids ? A.unit_ids[blockIdx.x] : blockIdx.x;
+  const uint32_t unit = A.unit_ids ? A.unit_ids[PFA_UNIT_IDX] : PFA_UNIT_IDX;
   const pfa_desc D = A.descs[unit];
   const bool cds = HAS_CDS && (D.flags & PFA_FLAG_CDS) != 0u;
   const uint32_t N = D.n_rows, L = D.n_sites;
   if (N == 0u || L == 0u) return;
   const uint32_t n_tiles = (L + TW - 1u) / TW;
-  const uint32_t t0 = blockIdx.y * A.tiles_per_chunk;
+  const uint32_t t0 = PFA_CHUNK_IDX * A.tiles_per_chunk;
   if (t0 >= n_tiles) return;
   const uint32_t t1 = umin(t0 + A.tiles_per_chunk, n_tiles);
 
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   acc_bad = wave_sum(acc_bad);
   acc_H = wave_sum(acc_H);
   const kernarg_ptr_t K = kernargs_again();
-  const uint32_t rep_off = (blockIdx.y & K->rep_mask) * K->rep_stride;   // this chunk's output replica
+  const uint32_t rep_off = (PFA_CHUNK_IDX & K->rep_mask) * K->rep_stride;   // this chunk's output replica
   if (lane == 0u) {
     pfa_result* const R = replica(K->results, rep_off) + unit;
     // seg_sites and sfs_bad are neighbours in the record: one 64-bit add (neither can carry: < 2^32 sites)
@@ -442,7 +442,7 @@ static int launch_one(const LaunchCfg& c, const ScanArgs& a, hipStream_t st) {
                                 (int)c.lds_bytes));
     lds_limit_set = c.lds_bytes;
   }
-  hipLaunchKernelGGL(kern, dim3(c.n_units, c.n_chunks, 1), dim3(64, 1, 1), c.lds_bytes, st, a);
+  hipLaunchKernelGGL(kern, PFA_GRID(c.n_units, c.n_chunks), dim3(64, 1, 1), c.lds_bytes, st, a);
   PFA_HIP(hipGetLastError());
   return PFA_OK;
 }
