@@ -592,7 +592,9 @@ def cpu_baseline(args, hw):
         if dt >= args.cpu_seconds:
             break
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    T = max(1, cores)
+    # the CPUs this process may keep busy: its affinity mask capped by the control group's CPU quota (128 threads inside a
+    # 16-CPU quota are 16 CPUs' worth of work and a throttled process)
+    T = max(1, min(cores, int(_lib.load().pfa_host_cpu_share(None, None))))
     per = max(1, n_mat // T)
     slices = [bases[(k % (n_mat // per)) * per * N * stride:((k % (n_mat // per)) + 1) * per * N * stride] for k in range(T)]
 
@@ -616,7 +618,7 @@ def cpu_baseline(args, hw):
         dt_py = time.perf_counter() - tp
         if dt_py >= min(args.cpu_seconds, 5.0):
             break
-    DETAIL["cpu_baseline"] = {"all_cores": f"the same scalar C scan on {T} host threads (every CPU this process may use) for {dt_mt:.1f} s",
+    DETAIL["cpu_baseline"] = {"all_cores": f"the same scalar C scan on {T} host threads (every CPU this process may keep busy: {cores} in its affinity mask, CPU quota included) for {dt_mt:.1f} s",
                               "pure_python": f"oracle/polyfasta_oracle.py (the reference's loop structure: getvarsites + polymorphism) on {n_py} alignment(s) "
                                              f"of the same workload for {dt_py:.1f} s; S = {poly[0]} = the GPU's: {poly[0] == int(s[0])}"}
     return {"value": done / dt, "unit": "alignments/s", "cores": 1, "kind": "port",

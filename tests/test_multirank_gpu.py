@@ -217,7 +217,7 @@ def test_bench_with_two_ranks_on_one_gpu(gpu):
     assert sum(st["files"]) == 192 and min(st["claims"]) >= 1 and max(st["wall"]) <= e["s"] * 1.001 + 1e-6
     # rank 0 alone on the same files (the single-process path), same rows
     assert e["solo_rank0_same_files"]["rows_equal"] is True and e["solo_rank0_same_files"]["best"] > 0
-    assert e["host_read_ceiling_alignments_per_s"] > 1e5 and set(j["roofline"]["end_to_end"]) == {"ranks2", "solo"}
+    assert e["host_read_ceiling_alignments_per_s"] > 1e4 and set(j["roofline"]["end_to_end"]) == {"ranks2", "solo"}
     assert len(lines[0]) < 8192
 
 
