@@ -411,3 +411,81 @@ def test_unreadable_directory_entry_dies_where_the_reference_dies(gpu, tmp_path)
         if "file" in want:
             same_transcript(open(tmp_path / "res.csv").read(), want["file"])
             os.unlink(tmp_path / "res.csv")
+
+
+def test_directory_of_large_alignments_every_row_every_column(gpu, tmp_path, monkeypatch):
+    """Files of hundreds to thousands of sequences through the command line (the reference has no row limit,
+    PolyFastA.py:252-261, :284-315): the ingest hands them to the row-chunked kernel — its 56-bit coding form above 2 048
+    rows — next to small files on the classic kernels in the same batches; per-population matrices of 300 and 1 500 rows.
+    `--cds --jc`, plain and `-p pop1,pop2 --cds`: every row, every column against the checker."""
+    import ctypes
+    import numpy as np
+    from oracle import c_oracle
+    from oracle import polyfasta_oracle as orc
+    from polyfasta_amd import _lib, scan
+    from polyfasta_amd import ingest
+    shapes = [(3000, 9000), (50, 9000), (700, 30000), (600, 20001), (129, 3000), (2049, 999), (64, 9000), (1000, 9000)]
+    launched = []          # the kernels of every batch's plan
+    fetch = ingest.IngestBatch.fetch
+
+    def spy(self, coding, want_sfs=False):
+        if self._plan:
+            launched.append(_lib.load().pfa_plan_describe(self._plan).decode())
+        return fetch(self, coding, want_sfs)
+    monkeypatch.setattr(ingest.IngestBatch, "fetch", spy)
+    root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (1 << 30) else str(tmp_path)
+    d = os.path.join(root, f"pfa_large_{os.getpid()}")
+    os.makedirs(d)
+    try:
+        mats, names = [], []
+        for i, (N, L) in enumerate(shapes):
+            p = synth.make_params(N, 0.01)
+            stride = scan.row_stride_for(L, 128)
+            sp = _lib.SynthParamsC(seed=900 + i, first_aln=0, n_aln=1, n_rows=N, n_sites=L, row_stride=stride, seg_thresh=p.seg_thresh,
+                                   tri_thresh=p.tri_thresh, n_units=len(p.units), coding=1)
+            bases = np.zeros(N * stride, dtype=np.uint8)
+            _lib.check(_lib.load().pfa_synth_fill_host(_lib.ptr(bases), ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(p.cdf)),
+                                                       _lib.ptr(np.ascontiguousarray(p.units))))
+            m = np.ascontiguousarray(bases.reshape(N, stride)[:, :L])
+            if i == 0:
+                m[5::7, 600:603] = np.frombuffer(b"TGA", dtype=np.uint8)      # a stop codon in every seventh row
+                m[11, 3000:3009] = ord("N")
+            if i == 2:
+                m[::3, 12345] = ord("-")
+            mats.append(m)
+            names.append(f"aln{i:02d}_{N}x{L}.fa")
+            hdr = synth.headers_for(N, 2)
+            with open(os.path.join(d, names[-1]), "wb") as fh:
+                fh.write(b"".join(b">" + h.encode() + b"\n" + m[r].tobytes() + b"\n" for r, h in enumerate(hdr)))
+        cache = {}
+
+        def want_rows(keys, cds, jc):
+            out = []
+            for i, (N, L) in enumerate(shapes):
+                for key in keys or [None]:
+                    rows = None if key is None else np.arange(int(key[-1]) - 1, N, 2, dtype=np.uint32)
+                    ck = (i, key, cds)
+                    if ck not in cache:
+                        cache[ck] = c_oracle.scan(mats[i], rows=rows, cds=cds)
+                    out.append(orc.row_from_counts(names[i], key or "NA", N if rows is None else len(rows), L, cache[ck], cds, jc))
+            return out
+
+        for argv, keys, cds, jc in ((["--cds", "--jc"], None, True, True), ([], None, False, False),
+                                    (["-p", "pop1,pop2", "--cds"], ["pop1", "pop2"], True, False)):
+            rc, out = run_cli(["-d", d, "-s"] + argv)
+            assert rc == 0
+            got = out.rstrip("\n").split("\n")
+            want = want_rows(keys, cds, jc)
+            assert len(got) == len(want), (argv, len(got), len(want))
+            bad = [(a, b, C.row_matches(a, b, cds, jc)) for a, b in zip(got, want) if a != b and C.row_matches(a, b, cds, jc)]
+            assert not bad, (argv, len(bad), bad[:3])
+            text = " | ".join(launched)
+            del launched[:]
+            assert "scan_tall_kernel" in text and "pfa::scan_kernel<" in text, text
+            assert ("wide=1" in text) == (cds and keys is None), text      # 3 000 and 2 049 coding rows; the populations are halves
+        # the inputs did what they were meant to: stops counted in the 3 000-row file, every file varies
+        first = want_rows(None, True, False)[0].split(",")
+        assert int(first[-1]) >= 1 and int(first[4]) == 3000
+        assert all(int(r.split(",")[4]) > 0 for r in want_rows(None, False, False))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
