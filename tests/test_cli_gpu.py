@@ -483,6 +483,15 @@ def test_directory_of_large_alignments_every_row_every_column(gpu, tmp_path, mon
             del launched[:]
             assert "scan_tall_kernel" in text and "pfa::scan_kernel<" in text, text
             assert ("wide=1" in text) == (cds and keys is None), text      # 3 000 and 2 049 coding rows; the populations are halves
+        # the same alignments on standard input (--pipe: the in-memory batch path, PolyFastA.py:96-100, :230-236)
+        for i in (0, 3):
+            N, L = shapes[i]
+            text = open(os.path.join(d, names[i]), "rb").read()
+            rc, out = run_cli(["--pipe", "-n", "big", "-p", "pop2,pop1", "--cds", "--jc", "-s"], stdin_bytes=text, monkeypatch=monkeypatch)
+            assert rc == 0
+            want = [orc.row_from_counts("big", key, len(range(int(key[-1]) - 1, N, 2)), L, cache[(i, key, True)], True, True) for key in ("pop2", "pop1")]
+            got = out.rstrip("\n").split("\n")
+            assert len(got) == 2 and not [C.row_matches(a, b, True, True) for a, b in zip(got, want) if a != b and C.row_matches(a, b, True, True)], (got, want)
         # the inputs did what they were meant to: stops counted in the 3 000-row file, every file varies
         first = want_rows(None, True, False)[0].split(",")
         assert int(first[-1]) >= 1 and int(first[4]) == 3000
