@@ -498,3 +498,45 @@ def test_directory_of_large_alignments_every_row_every_column(gpu, tmp_path, mon
         assert all(int(r.split(",")[4]) > 0 for r in want_rows(None, False, False))
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_one_chromosome_scale_alignment(gpu, tmp_path):
+    """Few sequences, tens of millions of sites (the reference has no length limit either, PolyFastA.py:252-261): a file far
+    larger than an ingest slot, more 256-site tiles than a grid dimension holds (78 126 > 65 535: several tiles per
+    workgroup are forced), coding and not.  Every column of the row against the checker."""
+    import ctypes
+    import numpy as np
+    from oracle import c_oracle
+    from oracle import polyfasta_oracle as orc
+    from polyfasta_amd import _lib, scan
+    root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (2 << 30) else str(tmp_path)
+    d = os.path.join(root, f"pfa_chrom_{os.getpid()}")
+    os.makedirs(d)
+    try:
+        for i, (N, L, cds) in enumerate(((8, 20_000_003, False), (6, 19_999_998, True))):
+            p = synth.make_params(N, 0.01)
+            stride = scan.row_stride_for(L, 128)
+            sp = _lib.SynthParamsC(seed=77 + i, first_aln=0, n_aln=1, n_rows=N, n_sites=L, row_stride=stride, seg_thresh=p.seg_thresh,
+                                   tri_thresh=p.tri_thresh, n_units=len(p.units), coding=int(cds))
+            bases = np.zeros(N * stride, dtype=np.uint8)
+            _lib.check(_lib.load().pfa_synth_fill_host(_lib.ptr(bases), ctypes.byref(sp), _lib.ptr(np.ascontiguousarray(p.cdf)),
+                                                       _lib.ptr(np.ascontiguousarray(p.units))))
+            m = bases.reshape(N, stride)[:, :L]
+            m[1, L - 1] = ord("N") if m[0, L - 1] != ord("N") else ord("A")      # the very last site varies
+            name = os.path.join(d, f"chrom{i}.fa")
+            with open(name, "wb") as fh:
+                for r in range(N):
+                    fh.write(b">s%d\n" % r)
+                    fh.write(m[r].tobytes())
+                    fh.write(b"\n")
+            o = c_oracle.scan(m, cds=cds)
+            for jc in (False, True):
+                rc, out = run_cli(["-f", name, "-s"] + (["--cds"] if cds else []) + (["--jc"] if jc else []))
+                assert rc == 0
+                want = orc.row_from_counts(f"chrom{i}.fa", "NA", N, L, o, cds, jc)
+                got = out.rstrip("\n")
+                assert got == want or C.row_matches(got, want, cds, jc) is None, (got, want)
+            assert o["S"] > 100_000
+            del bases, m
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
