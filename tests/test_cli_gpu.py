@@ -540,3 +540,47 @@ def test_one_chromosome_scale_alignment(gpu, tmp_path):
             del bases, m
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_hundred_thousand_tiny_files(gpu, tmp_path):
+    """BASELINE config 5's file count with alignments of a few short sequences (2 to 7 rows, 30 to 93 sites; many without a
+    single variable site, many with N = 2 or 3 where Tajima's D is "NA", PolyFastA.py:508-511, :522-534): the per-file costs of
+    the ingest, plans of tens of thousands of units per batch, the formatter at scale.  Plain and `--cds --jc`: every row."""
+    import numpy as np
+    from oracle import c_oracle
+    from oracle import polyfasta_oracle as orc
+    M = 100_000
+    root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (1 << 30) else str(tmp_path)
+    d = os.path.join(root, f"pfa_tiny_{os.getpid()}")
+    os.makedirs(d)
+    try:
+        rng = np.random.default_rng(2026)
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        mats = []
+        for i in range(M):
+            n, L = int(rng.integers(2, 8)), 3 * int(rng.integers(10, 32))
+            m = np.repeat(acgt[rng.integers(0, 4, L)][None, :], n, axis=0)
+            k = int(rng.integers(0, 4))                       # 0 .. 3 mutated cells: a quarter of the files do not vary
+            if k:
+                m[rng.integers(0, n, k), rng.integers(0, L, k)] = acgt[rng.integers(0, 4, k)]
+            if i % 997 == 0:
+                m[0, 0] = ord("N")
+            mats.append(m)
+            with open(os.path.join(d, f"t{i:06d}.fa"), "wb") as fh:
+                fh.write(b"".join(b">s%d\n" % r + m[r].tobytes() + b"\n" for r in range(n)))
+        for argv, cds, jc in (([], False, False), (["--cds", "--jc"], True, True)):
+            out_path = os.path.join(d, "..", f"pfa_tiny_{os.getpid()}.csv")
+            rc, _ = run_cli(["-d", d, "-s", "-o", out_path] + argv)
+            assert rc == 0
+            got = open(out_path).read().rstrip("\n").split("\n")              # (--silent: no header line)
+            os.unlink(out_path)
+            assert len(got) == M
+            n_na = 0
+            for i, (a, m) in enumerate(zip(got, mats)):
+                want = orc.row_from_counts(f"t{i:06d}.fa", "NA", m.shape[0], m.shape[1], c_oracle.scan(m, cds=cds), cds, jc)
+                assert a == want or C.row_matches(a, want, cds, jc) is None, (i, a, want)
+                n_na += a.split(",")[-2 if cds else -1] == "NA"
+            assert n_na > M // 4        # no variable site, or two or three sequences
+            assert cli.last_stats["files"] == M
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
