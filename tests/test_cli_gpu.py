@@ -584,3 +584,42 @@ def test_hundred_thousand_tiny_files(gpu, tmp_path):
             assert cli.last_stats["files"] == M
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_a_million_sequences_in_one_file(gpu, tmp_path):
+    """2^20 sequences of 15 sites in one file (the ABI's row limit; the reference has none, PolyFastA.py:252-261): the record
+    index of a million headers, the population split over them (`-p popA,popB`: half a million rows each), 64-bit H,
+    the coding pass; every column against the checker.  One sequence more is refused loudly, never answered wrongly."""
+    import numpy as np
+    from oracle import c_oracle
+    from oracle import polyfasta_oracle as orc
+    from polyfasta_amd import _lib
+    N, L = _lib.PFA_MAX_ROWS, 15
+    rng = np.random.default_rng(5)
+    m = np.repeat(np.frombuffer(b"ATGGCTAAAGGTCTA", dtype=np.uint8)[None, :], N, axis=0)
+    for col, frac, alt in ((2, 0.3, b"A"), (4, 0.001, b"T"), (5, 0.5, b"G"), (9, 0.02, b"C"), (10, 0.02, b"A"), (14, 1e-5, b"N")):
+        m[rng.random(N) < frac, col] = ord(alt)
+    root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (1 << 30) else str(tmp_path)
+    path = os.path.join(root, f"pfa_million_{os.getpid()}.fa")
+    try:
+        hdr = [b">pop%s_%d\n" % (b"A" if r % 2 == 0 else b"B", r) for r in range(N)]
+        with open(path, "wb") as fh:
+            fh.write(b"".join(h + m[r].tobytes() + b"\n" for r, h in enumerate(hdr)))
+        name = os.path.basename(path)
+        for argv, keys, cds, jc in ((["--cds", "--jc"], None, True, True), (["-p", "popA,popB"], ["popA", "popB"], False, False)):
+            rc, out = run_cli(["-f", path, "-s"] + argv)
+            assert rc == 0
+            got = out.rstrip("\n").split("\n")
+            want = []
+            for key in keys or [None]:
+                rows = None if key is None else np.arange(0 if key == "popA" else 1, N, 2, dtype=np.uint32)
+                o = c_oracle.scan(m, rows=rows, cds=cds)
+                want.append(orc.row_from_counts(name, key or "NA", N if rows is None else len(rows), L, o, cds, jc))
+            assert len(got) == len(want) and all(a == b or C.row_matches(a, b, cds, jc) is None for a, b in zip(got, want)), (got, want)
+        with open(path, "ab") as fh:
+            fh.write(b">one_more\n" + m[0].tobytes() + b"\n")
+        with pytest.raises(_lib.PfaError, match="rows"):
+            run_cli(["-f", path, "-s"])
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
