@@ -238,3 +238,36 @@ def test_bench_prints_its_line_when_the_multi_rank_end_to_end_leg_hangs(gpu):
     assert "rank 1 of 2" in p.stderr and "last stage:" in p.stderr
     import glob
     assert not glob.glob("/dev/shm/pfa_e2e_ranks_*"), "the leg's tmpfs directory was left behind"
+
+
+@pytest.mark.parametrize("extra", [["--cds", "--jc", "-p", "pop1,pop2"], []])
+def test_three_rank_cli_over_a_heterogeneous_directory(gpu, tmp_path, extra):
+    """Three ranks draining one queue of very unlike files — 300 tiny ones, alignments of 700 and 3 000 sequences (the
+    row-chunked kernel and its 56-bit coding form on whichever rank claims them), an empty file, a file that is not FASTA, one
+    with unequal lengths: the single process's CSV byte for byte (PolyFastA.py:104, :117-140)."""
+    d = _make_dir(tmp_path, n_files=23)
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i in range(300):
+        n, L = int(rng.integers(2, 6)), 3 * int(rng.integers(10, 30))
+        m = np.repeat(acgt[rng.integers(0, 4, L)][None, :], n, axis=0)
+        m[rng.integers(0, n), rng.integers(0, L)] = ord("A")
+        (d / f"h{i:03d}.fa").write_bytes(b"".join(b">pop%d_s%d\n" % (1 + r % 2, r) + m[r].tobytes() + b"\n" for r in range(n)))
+    for name, n, L in (("big_a.fa", 700, 6000), ("big_b.fa", 3000, 3000)):
+        p = synth.make_params(n, 0.01)
+        (d / name).write_text(synth.to_fasta_text(synth.headers_for(n, 2), synth.synth_alignment(77, n, L, p, coding=True)))
+    (d / "empty.fa").write_bytes(b"")
+    argv = ["-d", str(d), "-s"] + extra
+    want = _single(argv)
+    assert want.count("\n") >= 325 and "# file" in want
+    out = tmp_path / "rank0.csv"
+    port = dist._free_port()
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_cli_rank_worker.py"), str(out)] + argv,
+                                      env=env, cwd=ROOT, stderr=subprocess.PIPE))
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err.decode()[-3000:]
+    assert open(out).read() == want
