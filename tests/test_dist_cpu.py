@@ -37,7 +37,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])      # (8: the node north_star names; seven non-root ranks to merge)
 def test_two_rank_gloo_gather(tmp_path, world):
     out = tmp_path / "merged.json"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
