@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 5
+#define PFA_ABI_VERSION 6
 
 /* error codes */
 #define PFA_OK 0
@@ -474,6 +474,15 @@ int pfa_host_free(void* p);
  * With both arguments NULL: that number.  With a cgroup mount point and a /proc/<pid>/cgroup-style file: the quota
  * found there alone, in CPUs (1e9 = none) — for tests. */
 double pfa_host_cpu_share(const char* cgroup_root, const char* proc_cgroup);
+/* The loader threads of a single process's ingest are spread round robin over the last-level-cache domains of the CPUs the
+ * process may run on (a CCD of an EPYC: 8 cores and their sibling threads), each free to move inside its domain: left to the
+ * scheduler, 16 loaders now and then crowd onto a few domains or onto sibling threads, and the files -> CSV rate of a run
+ * swings by 10-40 % (profiles/r04_loader_l3_spread_ab.txt).  Not for the ranks of a multi-GPU job (measured slightly slower
+ * there) nor for a mask that spans sockets.  PFA_PIN_LOADERS=0 switches it off, =l3 forces it.  No reference
+ * counterpart (one thread).  This entry reports the grouping — for tests: `cpu_sys_root` = a /sys/devices/system/cpu-style
+ * tree (cpu<N>/cache/index3/id), NULL = the machine's; domain_of[i] = domain index (in mask order) of the i-th CPU of
+ * the affinity mask, for at most `cap` CPUs.  Returns the number of domains, 0 when sysfs does not say. */
+int pfa_host_l3_domains(const char* cpu_sys_root, int* domain_of, int cap);
 
 #ifdef __cplusplus
 }

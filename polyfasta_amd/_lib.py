@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PFA_LIB") or os.path.join(_HERE, "libpfa_hip.so")   # PFA_LIB: timing experiments with other builds
 
-PFA_ABI_VERSION = 5
+PFA_ABI_VERSION = 6
 PFA_NO_ROW_IDX = 0xFFFFFFFF
 PFA_FLAG_CDS = 1
 PFA_WANT_VAR_BITMAP = 1
@@ -124,6 +124,7 @@ _PROTOTYPES = {
     "pfa_plan_tile_width": (ctypes.c_uint32, [_vp]),
     "pfa_plan_n_launches": (ctypes.c_uint32, [_vp]),
     "pfa_plan_describe": (ctypes.c_char_p, [_vp]),
+    "pfa_host_l3_domains": (ctypes.c_int, [ctypes.c_char_p, _vp, ctypes.c_int]),
     "pfa_plan_sfs_words": (ctypes.c_uint64, [_vp]),
     "pfa_plan_destroy": (None, [_vp]),
     "pfa_scan_batch": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, ctypes.c_uint32, _vp, ctypes.c_size_t,

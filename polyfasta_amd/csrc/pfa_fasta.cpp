@@ -317,6 +317,60 @@ double cgroup_cpu_quota(const char* cgroup_root, const char* proc_cgroup) {
   return best;
 }
 
+// the CPUs of the process's affinity mask grouped by `key(cpu)` (a number read from sysfs; < 0: unreadable), in mask order
+static std::vector<std::vector<int>> cpu_groups(const char* sys_root, long (*key)(const std::string& cpu_dir)) {
+  std::vector<std::vector<int>> out;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) != 0) return out;
+  std::vector<long> keys;
+  for (int c = 0; c < CPU_SETSIZE; ++c) {
+    if (!CPU_ISSET(c, &set)) continue;
+    const long k = key(std::string(sys_root) + "/cpu" + std::to_string(c) + "/");
+    if (k < 0) return {};
+    const size_t i = (size_t)(std::find(keys.begin(), keys.end(), k) - keys.begin());
+    if (i == keys.size()) { keys.push_back(k); out.emplace_back(); }
+    out[i].push_back(c);
+  }
+  return out;
+}
+
+static bool pin_to_group(const std::vector<std::vector<int>>& groups, uint32_t k) {
+  if (groups.empty()) return false;
+  cpu_set_t one;
+  CPU_ZERO(&one);
+  for (int c : groups[k % groups.size()]) CPU_SET(c, &one);
+  return pthread_setaffinity_np(pthread_self(), sizeof(one), &one) == 0;
+}
+
+bool pin_to_core(uint32_t k) {
+  static const std::vector<std::vector<int>> cores = cpu_groups("/sys/devices/system/cpu", [](const std::string& d) -> long {
+    const double pkg = read_number(d + "topology/physical_package_id"), core = read_number(d + "topology/core_id");
+    return pkg < 0 || core < 0 ? -1 : ((long)pkg << 20) | (long)core;
+  });
+  return pin_to_group(cores, k);
+}
+
+std::vector<std::vector<int>> l3_domains(const char* sys_root) {
+  return cpu_groups(sys_root, [](const std::string& d) -> long { return (long)read_number(d + "cache/index3/id"); });
+}
+
+bool pin_to_l3(uint32_t k) {
+  // (the mask as it is when the first loader of the process starts: a rank has bound itself to its CPUs by then).  A mask
+  // that spans sockets (nothing bound the process: no GPU topology, PFA_NO_AFFINITY) is left to the scheduler: dealing
+  // loaders out over both sockets puts half of them across the socket link from the pinned ring.
+  static const std::vector<std::vector<int>> domains = [] {
+    std::vector<std::vector<int>> d = l3_domains("/sys/devices/system/cpu");
+    long pkg = -1;
+    for (const std::vector<int>& g : d) {
+      const long p = (long)read_number("/sys/devices/system/cpu/cpu" + std::to_string(g.front()) + "/topology/physical_package_id");
+      if (pkg >= 0 && p != pkg) return std::vector<std::vector<int>>{};
+      pkg = p;
+    }
+    return d;
+  }();
+  return domains.size() > 1 && pin_to_group(domains, k);
+}
+
 double cpu_share() {
   if (const char* e = getenv("PFA_CPUS")) { const double v = atof(e); if (v > 0) return v; }
   cpu_set_t set;
@@ -332,6 +386,19 @@ double cpu_share() {
 }  // namespace pfa
 
 extern "C" {
+
+int pfa_host_l3_domains(const char* cpu_sys_root, int* domain_of, int cap) {
+  const std::vector<std::vector<int>> dom = pfa::l3_domains(cpu_sys_root ? cpu_sys_root : "/sys/devices/system/cpu");
+  if (domain_of) {
+    // position of every CPU in the affinity mask (ascending CPU number)
+    std::vector<std::pair<int, int>> cpus;
+    for (size_t d = 0; d < dom.size(); ++d)
+      for (int c : dom[d]) cpus.push_back({c, (int)d});
+    std::sort(cpus.begin(), cpus.end());
+    for (size_t i = 0; i < cpus.size() && (int)i < cap; ++i) domain_of[i] = cpus[i].second;
+  }
+  return (int)dom.size();
+}
 
 double pfa_host_cpu_share(const char* cgroup_root, const char* proc_cgroup) {
   if (!cgroup_root && !proc_cgroup) return pfa::cpu_share();

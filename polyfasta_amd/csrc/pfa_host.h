@@ -48,5 +48,13 @@ bool pack2_row(const uint8_t* src, uint64_t n, uint8_t* dst);
 double cpu_share();
 // the quota alone, for the whole control group (CPUs; a very large number when there is none)
 double cgroup_cpu_quota(const char* cgroup_root = "/sys/fs/cgroup", const char* proc_cgroup = "/proc/self/cgroup");
+// (timing experiment, PFA_PIN_LOADERS=<core stride>) pin the calling thread to the hardware threads of ONE physical core of the process's
+// affinity mask: the `k`-th distinct core, counted round the mask.  False when the topology cannot be read.
+bool pin_to_core(uint32_t k);
+// The default for the ingest's loader threads: the calling thread may run on the CPUs of the mask that share the `k`-th
+// last-level cache (a CCD of an EPYC: 8 cores and their sibling threads), counted round the mask — spread over the domains,
+// free inside one.  False (and nothing done) when the mask holds one such domain only or sysfs does not say.
+bool pin_to_l3(uint32_t k);
+std::vector<std::vector<int>> l3_domains(const char* sys_root);
 
 }  // namespace pfa

@@ -559,8 +559,16 @@ void worker_body(pfa_ingest* g) {
   }
 }
 
-void worker(pfa_ingest* g) {
+void worker(pfa_ingest* g, uint32_t t) {
   try {
+    // A single process's loaders are spread over the last-level-cache domains of its CPUs (pfa_host.h): two boxes of three gained
+    // 10-40 % in the median run, the third lost 1-2 % (profiles/r04_loader_l3_spread_ab.txt).  The ranks of a multi-GPU job
+    // (4 loaders each inside a 16-CPU quota) measured 4-7 % slower with it, inside a wide spread: left to the scheduler.
+    // PFA_PIN_LOADERS=0: never, =l3: always, =<n>: timing experiment, one physical core each, n cores apart.
+    const char* const pin = getenv("PFA_PIN_LOADERS");
+    const char* const ws = getenv("WORLD_SIZE");
+    if (pin ? strcmp(pin, "l3") == 0 : !(ws && atoi(ws) > 1)) (void)pin_to_l3(t);
+    else if (pin && atoi(pin) > 0) (void)pin_to_core(t * (uint32_t)atoi(pin));
     worker_body(g);
   } catch (const std::bad_alloc&) {
     std::lock_guard<std::mutex> lk(g->mu);
@@ -867,7 +875,7 @@ int pfa_ingest_feed(pfa_ingest* g, const uint32_t* file_idx, uint32_t n, int las
       g->direct = g->feed_closed && !getenv("PFA_INGEST_NO_DIRECT") && small_job();
       const uint32_t nt = std::max(1u, std::min<uint32_t>(g->want_threads, (uint32_t)std::max<size_t>(g->feed.size(), 1)));
       g->want_threads = nt;
-      for (uint32_t t = 0; t < nt; ++t) g->workers.emplace_back(pfa::worker, g);
+      for (uint32_t t = 0; t < nt; ++t) g->workers.emplace_back(pfa::worker, g, t);
       g->uploader = std::thread(pfa::uploader, g);
     }
     g->cv_work.notify_all();

@@ -154,7 +154,7 @@ def _cpulist(text):
 
 
 def gpu_local_cpus(local_rank: int, kfd_root="/sys/class/kfd/kfd/topology/nodes", pci_root="/sys/bus/pci/devices",
-                   drm_root="/sys/class/drm"):
+                   drm_root="/sys/class/drm", cpu_root=None):
     """CPUs next to GPU `local_rank` (its PCIe root's NUMA node), from sysfs alone — no HIP call, so a
     rank can bind itself before it touches the GPU.  The kfd topology lists the GPUs in HIP's device
     order (nodes this container may not read belong to other tenants and are skipped); a GPU node names
@@ -197,6 +197,20 @@ def gpu_local_cpus(local_rank: int, kfd_root="/sys/class/kfd/kfd/topology/nodes"
         return None
 
 
+def by_core(cpus, cpu_root="/sys/devices/system/cpu"):
+    """`cpus` ordered so that the hardware threads of one physical core are neighbours and cores keep their order
+    (topology/thread_siblings_list); unchanged when sysfs does not say."""
+    first = {}
+    try:
+        for c in cpus:
+            with open(os.path.join(cpu_root, f"cpu{c}", "topology", "thread_siblings_list")) as f:
+                sib = _cpulist(f.read())
+            first[c] = min(sib) if sib else c
+    except (OSError, ValueError):
+        return list(cpus)
+    return sorted(cpus, key=lambda c: (first[c], c))
+
+
 def bind_to_gpu_node(local_rank: int, local_world: int = 1, **roots):
     """Pin this process (and the loader threads it will start) to the CPUs next to its GPU; ranks
     that share a NUMA node split its CPUs evenly (rank r of the k ranks on that node takes every
@@ -213,10 +227,13 @@ def bind_to_gpu_node(local_rank: int, local_world: int = 1, **roots):
     allowed = sorted(set(mine) & os.sched_getaffinity(0))
     if not allowed:
         return None
-    # the ranks whose GPUs sit on the same CPUs share them out
+    # the ranks whose GPUs sit on the same CPUs share them out — by physical core: a node lists its CPUs as 0-63,128-191 (the
+    # second half are the sibling threads of the first), and slices of that list would give two ranks the same cores
     same = [r for r in range(max(local_world, 1)) if gpu_local_cpus(r, **roots) == mine] or [local_rank]
     k, me = len(same), same.index(local_rank) if local_rank in same else 0
-    share = allowed[me * len(allowed) // k:(me + 1) * len(allowed) // k] or allowed
+    if not os.environ.get("PFA_BIND_BY_CPU_LIST"):             # (timing experiments: slices of the node's CPU list as it stands)
+        allowed = by_core(allowed, roots.get("cpu_root", "/sys/devices/system/cpu"))
+    share = sorted(allowed[me * len(allowed) // k:(me + 1) * len(allowed) // k] or allowed)
     try:
         os.sched_setaffinity(0, share)
     except OSError:

@@ -250,3 +250,18 @@ def test_multi_node_launch_is_refused(monkeypatch):
     assert dist.single_node(4) and not dist.single_node(8)
     monkeypatch.delenv("LOCAL_WORLD_SIZE")
     assert dist.single_node(8)
+
+
+def test_ranks_of_one_node_share_its_cpus_by_physical_core(tmp_path):
+    """A NUMA node lists its CPUs as 0-3,8-11 (8-11 the sibling threads of 0-3): two ranks get two whole cores each, not the
+    first threads of all four cores and their siblings (dist.by_core)."""
+    root = tmp_path / "cpu"
+    for c in range(4):
+        for t in (c, c + 8):
+            (root / f"cpu{t}" / "topology").mkdir(parents=True)
+            (root / f"cpu{t}" / "topology" / "thread_siblings_list").write_text(f"{c},{c + 8}\n")
+    cpus = [0, 1, 2, 3, 8, 9, 10, 11]
+    order = dist.by_core(cpus, str(root))
+    assert order == [0, 8, 1, 9, 2, 10, 3, 11]
+    assert sorted(order[:4]) == [0, 1, 8, 9] and sorted(order[4:]) == [2, 3, 10, 11]
+    assert dist.by_core(cpus, str(tmp_path / "nope")) == cpus            # no topology: the list as it is

@@ -542,3 +542,24 @@ def test_cpu_share_follows_the_control_group_quota(tmp_path):
     four = float(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, LOCAL_WORLD_SIZE="4"), timeout=60).stdout)
     forced = float(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, PFA_CPUS="3.5"), timeout=60).stdout)
     assert 1.0 <= one <= len(os.sched_getaffinity(0)) and four == max(1.0, one / 4) and forced == 3.5
+
+
+def test_loader_threads_are_spread_over_last_level_cache_domains(tmp_path):
+    """pfa_host_l3_domains on a fake /sys/devices/system/cpu: the CPUs of the affinity mask grouped by cache/index3/id, in mask
+    order — what the ingest's loader threads are dealt out over (include/pfa.h); nothing when sysfs does not say."""
+    import ctypes
+    import numpy as np
+    from polyfasta_amd import _lib
+    lib = _lib.load()
+    cpus = sorted(os.sched_getaffinity(0))
+    root = tmp_path / "cpu"
+    for i, c in enumerate(cpus):
+        d = root / f"cpu{c}" / "cache" / "index3"
+        d.mkdir(parents=True)
+        (d / "id").write_text(f"{(i // 2) % 3 + 5}\n")           # domains 5, 6, 7 in turn, two CPUs at a time
+    dom = np.full(len(cpus), -1, dtype=np.int32)
+    n = lib.pfa_host_l3_domains(str(root).encode(), _lib.ptr(dom), len(cpus))
+    assert n == min(3, (len(cpus) + 1) // 2)
+    assert dom.tolist() == [(i // 2) % 3 for i in range(len(cpus))]
+    assert lib.pfa_host_l3_domains(str(tmp_path / "nope").encode(), None, 0) == 0
+    assert lib.pfa_host_l3_domains(None, None, 0) >= 0                    # the machine's own tree: whatever it says

@@ -90,10 +90,13 @@ def main():
               f"CPUs: {len(os.sched_getaffinity(0))}", flush=True)
         for rnd in range(a.rounds):
             for s in a.settings.split():
-                thr, wait = s.split(":")
+                thr, wait, pin = (s.split(":") + ["0"])[:3]     # threads : wait policy [: core stride of pinned loaders, PFA_PIN_LOADERS]
                 env = dict(os.environ)
                 env.pop("PFA_THREADS", None)
                 env.pop("PFA_WAIT", None)
+                env.pop("PFA_PIN_LOADERS", None)
+                if pin != "0":
+                    env["PFA_PIN_LOADERS"] = pin
                 if thr != "auto":
                     env["PFA_THREADS"] = thr
                 if wait != "auto":
@@ -104,7 +107,7 @@ def main():
                     print(f"round {rnd} {s}: FAILED rc={pr.returncode} {pr.stderr[-400:]}", flush=True)
                     continue
                 j = json.loads(pr.stdout.strip().splitlines()[-1])
-                print(f"round {rnd} {s:>10s}: loaders {j['threads']:2d}  best {M / j['best_s'] / 1e3:6.1f} k/s  median {M / j['median_s'] / 1e3:6.1f} k/s  first {j['first_s']:.3f} s  "
+                print(f"round {rnd} {s:>12s}: loaders {j['threads']:2d}  best {M / j['best_s'] / 1e3:6.1f} k/s  median {M / j['median_s'] / 1e3:6.1f} k/s  first {j['first_s']:.3f} s  "
                       f"throttled {j['throttled_periods']:3d} periods / {j['throttled_ms']:8.1f} ms  cpu {j['cpu_ms']:7.0f} ms over {j['wall_ms_warm']:6.0f} ms of wall = "
                       f"{j['cpu_ms'] / max(j['wall_ms_warm'], 1e-9):5.1f} CPUs", flush=True)
     finally:
