@@ -567,7 +567,8 @@ void worker(pfa_ingest* g, uint32_t t) {
     // PFA_PIN_LOADERS=0: never, =l3: always, =<n>: timing experiment, one physical core each, n cores apart.
     const char* const pin = getenv("PFA_PIN_LOADERS");
     const char* const ws = getenv("WORLD_SIZE");
-    if (pin ? strcmp(pin, "l3") == 0 : !(ws && atoi(ws) > 1)) (void)pin_to_l3(t);
+    // (a pool of one to three loaders — a run on a few files — has nothing to spread, and reading the topology costs a millisecond)
+    if (pin ? strcmp(pin, "l3") == 0 : !(ws && atoi(ws) > 1) && g->want_threads >= 4u) (void)pin_to_l3(t);
     else if (pin && atoi(pin) > 0) (void)pin_to_core(t * (uint32_t)atoi(pin));
     worker_body(g);
   } catch (const std::bad_alloc&) {
