@@ -66,7 +66,12 @@ def main():
     if a.child:
         return child(a.child, flags, a.reps)
     import numpy as np
-    from polyfasta_amd import _lib, scan, synth
+    from polyfasta_amd import _lib, dist, scan, synth
+    # the files' tmpfs pages belong next to the GPU, where the children (which bind themselves there) read them: written from
+    # the other socket they are read across the socket link, 145-150 k alignments/s instead of 200-215 k (PFA_WRITE_UNBOUND=1: that case)
+    if not os.environ.get("PFA_WRITE_UNBOUND"):
+        dist.bind_to_gpu_node(0, 1)
+        os.environ.pop("PFA_CPUS_ARE_MINE", None)
     lib = _lib.load()
     N, L, M = 50, a.sites, a.files
     coding = "--cds" in flags
