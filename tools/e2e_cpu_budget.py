@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--flags", default="")
     ap.add_argument("--sites", type=int, default=10000)
     ap.add_argument("--child", default=None)
+    ap.add_argument("--write-from", default="gpu", choices=["gpu", "other", "unbound"],
+                    help="which socket's CPUs write the files (= where their tmpfs pages land): the GPU's, the other one, wherever the scheduler puts this process")
     a = ap.parse_args()
     flags = a.flags.split() if a.flags else []
     if a.child:
@@ -69,9 +71,14 @@ def main():
     from polyfasta_amd import _lib, dist, scan, synth
     # the files' tmpfs pages belong next to the GPU, where the children (which bind themselves there) read them: written from
     # the other socket they are read across the socket link, 145-150 k alignments/s instead of 200-215 k (PFA_WRITE_UNBOUND=1: that case)
-    if not os.environ.get("PFA_WRITE_UNBOUND"):
+    if a.write_from == "gpu":
         dist.bind_to_gpu_node(0, 1)
         os.environ.pop("PFA_CPUS_ARE_MINE", None)
+    elif a.write_from == "other":                          # the pages land on the socket the GPU does NOT hang off
+        near = set(dist.gpu_local_cpus(0) or [])
+        far = sorted(os.sched_getaffinity(0) - near)
+        if near and far:
+            os.sched_setaffinity(0, far)
     lib = _lib.load()
     N, L, M = 50, a.sites, a.files
     coding = "--cds" in flags
@@ -92,7 +99,7 @@ def main():
                     fh.write(b"".join(h + mat[i].tobytes() + b"\n" for i, h in enumerate(hdr)))
         print(f"# {M} files of {N} x {L} in {root}; flags: {' '.join(flags) or '(plain)'}; cpu.max: "
               f"{open('/sys/fs/cgroup/cpu.max').read().strip() if os.path.exists('/sys/fs/cgroup/cpu.max') else 'n/a'}; "
-              f"CPUs: {len(os.sched_getaffinity(0))}", flush=True)
+              f"CPUs: {len(os.sched_getaffinity(0))}; files written from: {a.write_from}", flush=True)
         for rnd in range(a.rounds):
             for s in a.settings.split():
                 thr, wait, pin = (s.split(":") + ["0"])[:3]     # threads : wait policy [: core stride of pinned loaders, PFA_PIN_LOADERS]
@@ -100,7 +107,9 @@ def main():
                 env.pop("PFA_THREADS", None)
                 env.pop("PFA_WAIT", None)
                 env.pop("PFA_PIN_LOADERS", None)
-                if pin != "0":
+                if "=" in pin:                                   # VAR=x+VAR2=y instead of a pin setting
+                    env.update(kv.split("=", 1) for kv in pin.split("+"))
+                elif pin != "0":
                     env["PFA_PIN_LOADERS"] = pin
                 if thr != "auto":
                     env["PFA_THREADS"] = thr
@@ -112,7 +121,7 @@ def main():
                     print(f"round {rnd} {s}: FAILED rc={pr.returncode} {pr.stderr[-400:]}", flush=True)
                     continue
                 j = json.loads(pr.stdout.strip().splitlines()[-1])
-                print(f"round {rnd} {s:>12s}: loaders {j['threads']:2d}  best {M / j['best_s'] / 1e3:6.1f} k/s  median {M / j['median_s'] / 1e3:6.1f} k/s  first {j['first_s']:.3f} s  "
+                print(f"round {rnd} {s:>34s}: loaders {j['threads']:2d}  best {M / j['best_s'] / 1e3:6.1f} k/s  median {M / j['median_s'] / 1e3:6.1f} k/s  first {j['first_s']:.3f} s  "
                       f"throttled {j['throttled_periods']:3d} periods / {j['throttled_ms']:8.1f} ms  cpu {j['cpu_ms']:7.0f} ms over {j['wall_ms_warm']:6.0f} ms of wall = "
                       f"{j['cpu_ms'] / max(j['wall_ms_warm'], 1e-9):5.1f} CPUs", flush=True)
     finally:
