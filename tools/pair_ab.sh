@@ -6,5 +6,5 @@ PFA_PAIR=1 timeout -k 10 500 python3 -m pytest $R/tests/test_gpu_parity.py $R/te
 tail -2 $O/tests_pair.log
 PFA_PAIR=1 timeout -k 10 300 python3 $R/tools/soak_gpu.py ${SOAK:-600} 3000 > $O/soak_pair.log 2>&1 || { tail -30 $O/soak_pair.log; exit 1; }
 tail -1 $O/soak_pair.log
-ROUNDS=${ROUNDS:-3} $R/tools/ab_env.sh $O/ab_pair.txt "${WL:-headline c4 n200cds n100cds n200 n200:512}" "" "PFA_PAIR=1" > /dev/null
+ROUNDS=${ROUNDS:-3} $R/tools/ab_env.sh $O/ab_pair.txt "${WL:-c4 c4:8192}" "" "PFA_PAIR=1" > /dev/null
 cat $O/ab_pair.txt
