@@ -48,6 +48,8 @@ open(os.path.join(P, "r04_sq_counters_final_sources.txt"), "w").write("\n".join(
 
 subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), os.path.join(P, "r04_kernel_resources.json")], check=True,
                stdout=subprocess.DEVNULL)
+e2e = max(glob.glob(os.path.join(G, "prof_r4_e2e", "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)   # repack_kernel beside the scan
+shutil.copyfile(e2e, os.path.join(P, "r04_e2e_8192_files_kernel_stats.csv"))
 line = open(os.path.join(G, "r4_final_bench_n1.json")).read().strip().splitlines()[-1]
 json.loads(line)
 open(os.path.join(P, "r04_bench_n1.json"), "w").write(line + "\n")
