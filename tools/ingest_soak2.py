@@ -3,7 +3,7 @@
 other symbols, wrapped lines, CR / CRLF, unequal lengths, non-ASCII sequence characters), random loader threads and slot sizes;
 a random mode per directory (plain, --cds --jc, -p, -p --cds with a key nobody carries); EVERY COLUMN of every row and every
 comment line against the checker (the oracle's reader on the same text, the C scan, the oracle's own finishing math).
-usage: tools/ingest_soak2.py [seconds]"""
+usage: tools/ingest_soak2.py [seconds [first_seed]]   (directories are drawn from seeds first_seed + 1, + 2, ...: default 0)"""
 import io, os, sys, tempfile, shutil, time
 from contextlib import redirect_stdout
 import numpy as np
@@ -17,7 +17,7 @@ MODES = ([], ["--cds", "--jc"], ["-p", "pop1,pop2"], ["-p", "pop2,nopop,pop1", "
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t_end = time.time() + budget
-seed = 0
+seed = first_seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rows_checked = files_checked = 0
 while time.time() < t_end:
     seed += 1
@@ -102,4 +102,4 @@ while time.time() < t_end:
         shutil.rmtree(d, ignore_errors=True)
     if seed % 20 == 0:
         print(f"seed {seed}: {files_checked} files, {rows_checked} rows identical", flush=True)
-print(f"ingest soak: {files_checked} files over {seed} directories in four modes, {rows_checked} rows identical to the checker in every column")
+print(f"ingest soak: {files_checked} files over {seed - first_seed} directories (seeds {first_seed + 1} .. {seed}) in four modes, {rows_checked} rows identical to the checker in every column")
