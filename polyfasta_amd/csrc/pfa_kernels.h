@@ -74,16 +74,10 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // Grid: x = the bucket's units, y = chunks of consecutive tiles, so consecutive workgroups scan the same columns of different
-// units.  -DPFA_GRID_T (timing experiment): transposed, consecutive workgroups scan neighbouring chunks of one unit.
-#if defined(PFA_GRID_T)
-#define PFA_UNIT_IDX blockIdx.y
-#define PFA_CHUNK_IDX blockIdx.x
-#define PFA_GRID(units, chunks) dim3((chunks), (units), 1)
-#else
+// units (the transposed grid measured equal or slower, docs/TUNING.md).
 #define PFA_UNIT_IDX blockIdx.x
 #define PFA_CHUNK_IDX blockIdx.y
 #define PFA_GRID(units, chunks) dim3((units), (chunks), 1)
-#endif
 
 __device__ inline uint32_t mbcnt64(uint64_t m) {
   return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));

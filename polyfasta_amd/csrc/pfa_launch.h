@@ -18,12 +18,10 @@ struct LaunchCfg {
   bool mapped = false;       // ... units with a row-index list
   bool bitmaps = false;      // the plan wants per-site bitmaps
   bool wide = false;         // tall coding units above 2 048 rows: 56-bit per-site H
-  uint32_t nir = 0;          // scan_kernel: register tiles of this many 1-KiB loads (0: LDS-DMA)
 };
 
 int launch_classic(const LaunchCfg& c, const ScanArgs& a, hipStream_t st);
 int launch_tall(const LaunchCfg& c, const ScanArgs& a, hipStream_t st);
-uint32_t classic_reg_tile_class(uint32_t tw, uint32_t n_max);
 // load the translation unit's code object now (pfa_prewarm): hipFuncGetAttributes on one of its kernels
 void warm_classic();
 void warm_ingest();

@@ -517,11 +517,7 @@ static void finish_bucket(Bucket& b, const BucketKey& k, bool bitmaps, const pfa
     b.cfg.lds_bytes = tall_layout(b.rows_per_chunk, b.max_slots, b.hist_bins, b.cfg.cds, b.cfg.wide).total;
   } else {
     b.cfg.lds_bytes = lds_layout(k.tw, b.n_max, b.cfg.cds, b.cfg.mapped || bitmaps).total;
-    // register tiles (timing experiment until measured: PFA_REG_TILES=1): lean instantiations only
-    if (env_u32("PFA_REG_TILES", 0u) && !b.cfg.mapped && !bitmaps) b.cfg.nir = classic_reg_tile_class(k.tw, b.n_max);
   }
-  // (timing experiments: LDS a wavefront does not use, i.e. fewer wavefronts per CU with everything else equal)
-  if (getenv("PFA_LDS_PAD")) b.cfg.lds_bytes = std::min(kLdsPerCu, b.cfg.lds_bytes + env_u32("PFA_LDS_PAD", 0u));
   // chunking: enough single-wave workgroups to fill 256 CUs several times over, but whole
   // alignments per wave once the batch is large (fewer atomics).  96 single-wave workgroups per
   // CU measured best for the bench workload (10 tiles per chunk: 6.48 TB/s; 20 tiles 6.36,
@@ -550,12 +546,9 @@ static std::string describe(const pfa_plan* p) {
       snprintf(buf, sizeof buf, "pfa::scan_tall_kernel<cds=%d,mapped=%d,bitmaps=%d,wide=%d> units=%u n_max=%u rows_per_chunk=%u lds=%u tiles_per_chunk=%u",
                (int)b.cfg.cds, (int)(b.cfg.mapped || b.cfg.bitmaps), (int)(b.cfg.mapped || b.cfg.bitmaps), (int)b.cfg.wide, b.cfg.n_units, b.n_max, b.rows_per_chunk,
                b.cfg.lds_bytes, b.tiles_per_chunk);
-    else {
-      char regs[24] = "";
-      if (b.cfg.nir) snprintf(regs, sizeof regs, ",regs=%u", b.cfg.nir);
-      snprintf(buf, sizeof buf, "pfa::scan_kernel<cds=%d,mapped=%d,bitmaps=%d,tw=%u%s> units=%u n_max=%u lds=%u tiles_per_chunk=%u",
-               (int)b.cfg.cds, (int)(b.cfg.mapped || b.cfg.bitmaps), (int)b.cfg.bitmaps, b.cfg.tw, regs, b.cfg.n_units, b.n_max, b.cfg.lds_bytes, b.tiles_per_chunk);
-    }
+    else
+      snprintf(buf, sizeof buf, "pfa::scan_kernel<cds=%d,mapped=%d,bitmaps=%d,tw=%u> units=%u n_max=%u lds=%u tiles_per_chunk=%u",
+               (int)b.cfg.cds, (int)(b.cfg.mapped || b.cfg.bitmaps), (int)b.cfg.bitmaps, b.cfg.tw, b.cfg.n_units, b.n_max, b.cfg.lds_bytes, b.tiles_per_chunk);
     s += buf;
   }
   if (p->replicas > 1u) {

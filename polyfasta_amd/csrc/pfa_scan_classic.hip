@@ -17,14 +17,6 @@
 // getvarCDSsites :284-315, get_syn_nonsyn_cod_sites :319-434.
 #include "pfa_kernels.h"
 #include "pfa_launch.h"
-#ifndef PFA_T2_WIDE
-#define PFA_T2_WIDE 1
-#endif
-// timing experiments only (results are wrong): 1 = stop after tier 1, 2 = after the compaction, 3 = tier 2 reads its list entry and
-// row 0 but walks no column, 4 = tier 2 without its tail (no histogram / list update)
-#ifndef PFA_ABL
-#define PFA_ABL 0
-#endif
 
 namespace pfa {
 
@@ -32,21 +24,10 @@ namespace pfa {
 // MAPPED: the bucket's units read their rows through a row-index list (--pops).  BITMAPS: the plan
 // wants per-site bitmaps.  Both compile their branches — and the scalar registers they pin — out
 // of the batch path of the CLI and the bench.
-// NIR > 0 (round-4 experiment, -DPFA_REG_TILES_BUILD + PFA_REG_TILES=1; NOT built by default): the tile travels global ->
-// registers -> LDS instead of by LDS-DMA: `NIR` 16-byte registers per lane hold the NEXT tile (NIR x 1 KiB, the DMA's image:
-// instruction g = rows g RPI .. of the tile) while the current one is processed out of LDS, so a wavefront has a tile in flight
-// ALL the time at the same LDS (the LDS-DMA form has none while it processes: its one buffer is in use) — the "keep loads in
-// flight during the column walk" kernel of DESIGN §9.  Correct (parity suite), and equal or slower on every shape: headline
-// -0.6 %, config 4 -1 %, N = 100 +-1 %, N = 200 -1 .. -8 %, coding N = 100 -2 %, N = 200 -3.5 % (profiles/r04_reg_tiles_ab.txt);
-// the micro-benchmark agrees (tools/ubench/reg_prefetch.hip, profiles/r04_reg_prefetch_ubench.txt: the bytes in flight are not
-// what these shapes are short of).  Units of the launch have at most NIR x RPI rows.
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-
-template <int STAGE, bool HAS_CDS, bool MAPPED, bool BITMAPS, int TWP, int NIR = 0>
+template <int STAGE, bool HAS_CDS, bool MAPPED, bool BITMAPS, int TWP>
 __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   using G = Geo<TWP>;
-  static_assert(NIR == 0 || (!MAPPED && !BITMAPS && STAGE == 2), "register tiles: the lean instantiations only");
   static_assert(!HAS_CDS || TWP >= 128, "the coding pass works on 256- and 128-site tiles");
   static_assert(!BITMAPS || TWP == 256, "bitmaps are laid out per 256-site tile");
   constexpr uint32_t TW = G::TW;
@@ -136,45 +117,16 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       }
     }
   };
-  // ---------------- register tiles (NIR > 0): the same image through VGPRs
-  v4u regs[NIR ? NIR : 1];
-  auto load_regs = [&](uint32_t tile) {
-    const uint32_t c = lane % G::LPR, rr = lane / G::LPR;
-    const uint8_t* src = mat + (uint64_t)rr * D.row_stride + umin(tile * TW + 16u * c, D.row_stride - 16u);
-    const uint64_t step = (uint64_t)G::RPI * D.row_stride;
-    const uint32_t n_full = N / G::RPI;          // whole instructions (a scalar test each); only the one after them can be partial
-#pragma unroll
-    for (uint32_t g = 0; g < (uint32_t)NIR; ++g, src += step) {
-      if (g < n_full) regs[g] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(src));
-      else if (g == n_full && rr < N % G::RPI) regs[g] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(src));
-    }
-  };
-  auto regs_to_lds = [&]() {
-    const uint32_t rr = lane / G::LPR;
-    const uint32_t n_full = N / G::RPI;
-    uint8_t* const dst = tile8 + lane * 16u;
-#pragma unroll
-    for (uint32_t g = 0; g < (uint32_t)NIR; ++g) {
-      if (g < n_full) *reinterpret_cast<v4u*>(dst + g * 1024u) = regs[g];
-      else if (g == n_full && rr < N % G::RPI) *reinterpret_cast<v4u*>(dst + g * 1024u) = regs[g];
-    }
-  };
   // The tile of iteration t+1 is requested as soon as iteration t has read the last byte it needs
   // from the tile buffer; what is left of iteration t by then (register / table work of the coding
   // pass) runs under the loads.
-  if constexpr (NIR > 0) load_regs(t0);
-  else stage(t0);
+  stage(t0);
 
   const uint32_t steps = N / G::GROUPS, tail = N % G::GROUPS;
   for (uint32_t tile = t0; tile < t1; ++tile) {
     const uint32_t site0 = tile * TW;
     const uint32_t lim = umin(TW, L - site0);  // valid sites of this tile
-    if constexpr (NIR > 0) {
-      regs_to_lds();                              // (waits for this tile's loads; every read of the previous tile is done: the sync at the loop's end)
-      if (tile + 1u < t1) load_regs(tile + 1u);   // the next tile travels while this one is processed
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_lds_sync();
 
     // ---------------- tier 1: running AND / OR down the rows
@@ -203,12 +155,6 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       }
     }
     const uint32_t vd = va ^ vo;
-#if PFA_ABL == 1
-    acc_S += vd & 1u;
-    wave_lds_sync();
-    if (NIR == 0 && tile + 1u < t1) stage(tile + 1u);
-    continue;
-#endif
 
     // ---------------- compact the variable sites of the tile
     uint32_t P = 0u;
@@ -237,10 +183,6 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     P = __builtin_amdgcn_readfirstlane(P);
     acc_S += (lane == 0u) ? P : 0u;
     wave_lds_sync();
-#if PFA_ABL == 2
-    if (NIR == 0 && tile + 1u < t1) stage(tile + 1u);
-    continue;
-#endif
 
     // ---------------- tier 2: exact allele counts of the variable sites
     // LPS lanes per site walk its column: 4, or 8 in 128-site tiles with at most 8 variable sites (below).  Every row of a column
@@ -262,10 +204,6 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
         const uint8_t* colp = tile8 + s;
         const uint32_t x = colp[0], y = x ^ ((ent >> 8) & 0xFFu);
         uint32_t c1 = 0, c2 = 0;
-#if PFA_ABL == 3
-        acc_H += x + y;
-        continue;
-#endif
 #pragma unroll PFA_UNROLL_T2
         for (uint32_t r = ph; r < N; r += LPS) {
           const uint32_t v = colp[r * TW];
@@ -319,10 +257,6 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
             pres = (cA ? 1u : 0u) | (cC ? 2u : 0u) | (cT ? 4u : 0u) | (cG ? 8u : 0u);
           }
         }
-#if PFA_ABL == 4
-        acc_H += sumsq + second + pres;
-        continue;
-#endif
         if (act && ph == 0u) {
           const uint32_t hs = NN - sumsq;
           acc_H += hs;
@@ -339,9 +273,9 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     // with them the dependent LDS round trips of the walk (N = 200 coding 0.722 -> 0.740, N = 200 0.776 -> 0.786; the 256-site
     // tiles of units up to 64 rows have 16 rows per lane at most and more than 8 variable sites as a rule: nothing to gain)
     bool wide_walk = false;
-    if constexpr (TWP == 128u && PFA_T2_WIDE) wide_walk = P <= 8u;
+    if constexpr (TWP == 128u) wide_walk = P <= 8u;
     if (wide_walk) {
-      if constexpr (TWP == 128u && PFA_T2_WIDE) tier2(std::integral_constant<uint32_t, 8u>{});
+      if constexpr (TWP == 128u) tier2(std::integral_constant<uint32_t, 8u>{});
     } else {
       tier2(std::integral_constant<uint32_t, 4u>{});
     }
@@ -379,8 +313,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
           hget_uniform);
       // ---- nothing below reads the tile buffer: request the next tile now
       wave_lds_sync();
-      if constexpr (NIR == 0)
-        if (tile + 1u < t1) stage(tile + 1u);
+      if (tile + 1u < t1) stage(tile + 1u);
       cp.mono_and_single_columns(hget_lane);
       if (tile + 1u == n_tiles) cp.last_tile(L);
       // H of the last two sites, for the codons that straddle into the next tile
@@ -391,8 +324,7 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
       }
     } else {
       wave_lds_sync();   // every read of the tile buffer is done: request the next tile
-      if constexpr (NIR == 0)
-        if (tile + 1u < t1) stage(tile + 1u);
+      if (tile + 1u < t1) stage(tile + 1u);
     }
   }
 
@@ -433,9 +365,9 @@ __global__ void __launch_bounds__(64) classify_masks_kernel(const unsigned long 
 }
 
 // ---------------------------------------------------------------- launchers
-template <int STAGE, bool CDS, bool MAPPED, bool BITMAPS, int TW, int NIR = 0>
+template <int STAGE, bool CDS, bool MAPPED, bool BITMAPS, int TW>
 static int launch_one(const LaunchCfg& c, const ScanArgs& a, hipStream_t st) {
-  auto kern = scan_kernel<STAGE, CDS, MAPPED, BITMAPS, TW, NIR>;
+  auto kern = scan_kernel<STAGE, CDS, MAPPED, BITMAPS, TW>;
   static uint32_t lds_limit_set = 0;  // per instantiation; one process drives one device
   if (c.lds_bytes > lds_limit_set) {
     PFA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -453,29 +385,7 @@ static int launch_features(const LaunchCfg& c, const ScanArgs& a, hipStream_t st
     if (c.bitmaps) return launch_one<STAGE, CDS, true, true, TW>(c, a, st);   // the general instantiation
   }
   if (c.mapped) return launch_one<STAGE, CDS, true, false, TW>(c, a, st);
-#ifdef PFA_REG_TILES_BUILD   // (measured slower or equal on every shape, profiles/r04_reg_tiles_ab.txt: not built by default)
-  if constexpr (STAGE == 2 && TW == 128) {
-    if (c.nir == 13u) return launch_one<STAGE, CDS, false, false, TW, 13>(c, a, st);
-    if (c.nir == 25u) return launch_one<STAGE, CDS, false, false, TW, 25>(c, a, st);
-  }
-  if constexpr (STAGE == 2 && TW == 256) {
-    if (c.nir == 13u) return launch_one<STAGE, CDS, false, false, TW, 13>(c, a, st);
-  }
-#endif
   return launch_one<STAGE, CDS, false, false, TW>(c, a, st);
-}
-
-// register-tile classes: 1-KiB loads per tile the kernel is instantiated for (0: none serves such units)
-uint32_t classic_reg_tile_class(uint32_t tw, uint32_t n_max) {
-#ifndef PFA_REG_TILES_BUILD
-  (void)tw; (void)n_max;
-  return 0u;
-#else
-  const uint32_t rpi = 64u / (tw / 16u), need = (n_max + rpi - 1u) / rpi;
-  if (tw == 128u) return need <= 13u ? 13u : need <= 25u ? 25u : 0u;
-  if (tw == 256u) return need <= 13u ? 13u : 0u;
-  return 0u;
-#endif
 }
 
 int launch_classic(const LaunchCfg& c, const ScanArgs& a, hipStream_t st) {
