@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 6
+#define PFA_ABI_VERSION 7
 
 /* error codes */
 #define PFA_OK 0
@@ -117,12 +117,19 @@ uint32_t pfa_var_words_per_tile(uint32_t max_rows, uint32_t cds);
 
 /* ---- context -------------------------------------------------------------- */
 int pfa_abi_version(void);
+/* 16 hex digits: SHA-256 of the sources (csrc/ and this header) the library was compiled from.  The
+ * host side compares it with the tree it runs from (polyfasta_amd/_build.py: source_hash) and rebuilds
+ * or refuses, so new sources never run against an old library. */
+const char* pfa_build_id(void);
 int pfa_device_count(void);
 int pfa_init(int device);
 /* start bringing the HIP runtime up for `device` on a thread of the library's own and return at
  * once (a command line calls this before it loads its own modules; ~0.1 s of hipInit then runs
  * under them); pfa_init() waits for it.  Optional. */
 void pfa_prewarm(int device);
+/* wait for that thread (a no-op without one): a process that ends before its first pfa_init() must not
+ * leave while the thread is inside hipInit */
+void pfa_prewarm_join(void);
 int pfa_device_index(void); /* the device pfa_init() bound, or -1 */
 void pfa_shutdown(void);
 const char* pfa_last_error(void);
@@ -172,6 +179,18 @@ int pfa_plan_run_fetch(pfa_plan* plan, const uint8_t* d_bases, int variant, pfa_
 /* device pointer of the result records (n_desc x pfa_result) of the last run,
  * valid until that run is fetched (pfa_comm_all_gather_results() reads them) */
 int pfa_plan_results_dev(pfa_plan* plan, void** d_results, size_t* bytes);
+/* The set of distinct clean codons of every codon column of unit `unit`, in column order — `cods` of
+ * getvarCDSsites after its regex filter (PolyFastA.py:291, :301): sets_out[c] has bit (16 e0 + 4 e1 + e2)
+ * set (bases A=0 C=1 T=2 G=3, as pfa_classify_codon_mask) for every codon AAA..GGG — stop codons
+ * included, :295 removes nothing — that some row of the unit holds at sites 3c..3c+2; 0 = no clean codon
+ * (the column is "missing", :305; so is the partial last column of a length that is not a multiple of 3).
+ * ceil(n_sites / 3) words.  A re-scan of ONE unit with a kernel of its own, for the rare unit whose
+ * synonymous-site count lands on a two-decimal rounding tie: the reference accumulates that count
+ * column by column in floating point (:307) and prints round(x, 2) (:178), so on a tie the last bits of
+ * its accumulation decide the printed digit, and the host replays the accumulation from these sets
+ * (polyfasta_amd/stats.py: syn_sites_replay).  d_bases: the device matrices the plan was run on
+ * (NULL = those of its last pfa_plan_run, which must still be resident). */
+int pfa_plan_codon_sets(pfa_plan* plan, const uint8_t* d_bases, uint32_t unit, uint64_t* sets_out, uint64_t cap);
 uint32_t pfa_plan_n_tiles(const pfa_plan* plan);
 /* launch geometry of the plan's largest bucket (by bases read), for reports */
 uint32_t pfa_plan_tiles_per_chunk(const pfa_plan* plan);
@@ -349,9 +368,11 @@ int64_t pfa_format_plain_rows(const char* prefix_blob, const uint64_t* prefix_of
  * theta_S,theta_N,D_S,D_N,nstops\n", where name i = "file," and mid i = ",pop,N," are the caller's
  * text, sites_S = sum_k syn_num[k] / (3 k) and sites_N = (seqlen - 3 missing_cols) - sites_S are
  * printed through Python's round(x, 2), and the two polymorphism() tuples use them as their
- * sequence lengths.  syn_num: PFA_SYN_BINS words per row.  Same return convention as above. */
+ * sequence lengths.  syn_num: PFA_SYN_BINS words per row.  sites_s (may be NULL): per row, NaN or the
+ * synonymous-site count to use instead of the sum over the bins — the reference's own column-order
+ * accumulation replayed for a row on a rounding tie (pfa_plan_codon_sets).  Same return convention as above. */
 int64_t pfa_format_cds_rows(const char* name_blob, const uint64_t* name_off, const char* mid_blob, const uint64_t* mid_off,
-                            uint32_t n, const pfa_result* res, const uint32_t* syn_num, const uint32_t* n_rows,
+                            uint32_t n, const pfa_result* res, const uint32_t* syn_num, const double* sites_s, const uint32_t* n_rows,
                             const uint32_t* seqlen, const double* a1, const double* e1, const double* e2, int jc,
                             char* out, uint64_t cap, int64_t* bad_row);
 /* repr(float) of CPython 3 into out32 (at least 32 bytes, not NUL-terminated);
@@ -451,13 +472,13 @@ void pfa_ingest_close(pfa_ingest* ing);
 /* CSV rows of units named by index: row i is file `file_idx[i]` (name =
  * names_blob[names_off[f] .. names_off[f+1])), population key `key[i]` (PFA_NO_KEY:
  * "NA").  coding == 0: the 8-column row (pfa_format_plain_rows), else the 14-column
- * one (pfa_format_cds_rows; syn_num: PFA_SYN_BINS words per row).  Same return
- * convention as those two. */
+ * one (pfa_format_cds_rows; syn_num: PFA_SYN_BINS words per row; sites_s: its optional per-row
+ * override, may be NULL).  Same return convention as those two. */
 int64_t pfa_format_rows_indexed(const char* names_blob, const uint64_t* names_off,
                                 const char* keys_blob, const uint64_t* keys_off,
                                 uint32_t n, const uint32_t* file_idx, const uint32_t* key,
                                 const uint32_t* n_rows, const uint32_t* n_sites,
-                                const pfa_result* res, const uint32_t* syn_num,
+                                const pfa_result* res, const uint32_t* syn_num, const double* sites_s,
                                 const double* a1, const double* e1, const double* e2, int jc, int coding,
                                 char* out, uint64_t cap, int64_t* bad_row);
 

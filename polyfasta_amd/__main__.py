@@ -16,14 +16,19 @@ os.environ.setdefault("MKL_NUM_THREADS", "1")
 def _launcher_only(argv):
     """`--gpus N` with N > 1 and no launcher's environment: this process only starts the ranks (dist.spawn_ranks) and
     must not touch the GPU itself."""
+    # argparse accepts any unambiguous prefix of a long option (`--gpu 4`, `--g=4`: no other option starts with --g) and, when
+    # an option is repeated, its last occurrence
+    last = None
     for i, a in enumerate(argv):
-        v = argv[i + 1] if a == "--gpus" and i + 1 < len(argv) else a[len("--gpus="):] if a.startswith("--gpus=") else None
-        if v is not None:
-            try:
-                return int(v) > 1
-            except ValueError:
-                return False
-    return False
+        if a == "--":
+            break
+        name, eq, val = a.partition("=")
+        if len(name) >= 3 and "--gpus".startswith(name):
+            last = val if eq else (argv[i + 1] if i + 1 < len(argv) else None)
+    try:
+        return last is not None and int(last) > 1
+    except ValueError:
+        return False
 
 
 # A one-file run is dominated by start-up (interpreter, numpy, hipInit: bench.py `cold_start`).  The
@@ -61,9 +66,13 @@ finally:
     # The prewarm thread may still be inside hipInit when main() ends before its first scan (closed stdin at the prompt,
     # an unreadable directory, Ctrl-C): never leave the process under it — pfa_shutdown() joins it (and, on these paths
     # only, tears the runtime down in order).  After a normal run pfa_init() has joined it long ago.
-    if _prewarmed is not None and rc != 0:
+    # A run that ends well before any pfa_init (--help) only joins it.
+    if _prewarmed is not None:
         try:
-            _prewarmed.pfa_shutdown()
+            if rc != 0:
+                _prewarmed.pfa_shutdown()
+            else:
+                _prewarmed.pfa_prewarm_join()
         except Exception:       # noqa: BLE001
             pass
 # every row has been written: leave without the interpreter's and the HIP runtime's teardown (45 ms of a
@@ -82,7 +91,10 @@ if os.environ.get("PFA_EXIT") in ("shutdown", "reset"):      # timing experiment
 # Measured from a shell, one file, three alternating rounds (profiles/r04_shell_cold_start_ab.txt): one OpenBLAS thread
 # 217-359 ms (median 287), 256 threads 159-334 (median 230), one thread + 16-64 sleeping threads at exit 121-293 (median 165).
 # PFA_EXIT_KICK=0 switches it off.
-_kick = int(os.environ.get("PFA_EXIT_KICK", "32") or 0)
+try:
+    _kick = int(os.environ.get("PFA_EXIT_KICK", "32") or 0)
+except ValueError:              # (a run that has succeeded does not fail over this)
+    _kick = 0
 if _kick > 0:
     try:
         import threading

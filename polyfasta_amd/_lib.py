@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PFA_LIB") or os.path.join(_HERE, "libpfa_hip.so")   # PFA_LIB: timing experiments with other builds
 
-PFA_ABI_VERSION = 6
+PFA_ABI_VERSION = 7
 PFA_NO_ROW_IDX = 0xFFFFFFFF
 PFA_FLAG_CDS = 1
 PFA_WANT_VAR_BITMAP = 1
@@ -95,9 +95,11 @@ class PfaError(RuntimeError):
 _vp = ctypes.c_void_p
 _PROTOTYPES = {
     "pfa_abi_version": (ctypes.c_int, []),
+    "pfa_build_id": (ctypes.c_char_p, []),
     "pfa_device_count": (ctypes.c_int, []),
     "pfa_init": (ctypes.c_int, [ctypes.c_int]),
     "pfa_prewarm": (None, [ctypes.c_int]),
+    "pfa_prewarm_join": (None, []),
     "pfa_device_index": (ctypes.c_int, []),
     "pfa_shutdown": (None, []),
     "pfa_last_error": (ctypes.c_char_p, []),
@@ -117,6 +119,7 @@ _PROTOTYPES = {
     "pfa_plan_fetch": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pfa_plan_run_fetch": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pfa_plan_results_dev": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_size_t)]),
+    "pfa_plan_codon_sets": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_uint64]),
     "pfa_plan_n_tiles": (ctypes.c_uint32, [_vp]),
     "pfa_plan_tiles_per_chunk": (ctypes.c_uint32, [_vp]),
     "pfa_plan_lds_bytes": (ctypes.c_uint32, [_vp]),
@@ -133,7 +136,7 @@ _PROTOTYPES = {
                                               ctypes.c_uint32, _vp, ctypes.c_uint64]),
     "pfa_format_plain_rows": (ctypes.c_int64, [_vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
                                                _vp, ctypes.c_uint64, _vp]),
-    "pfa_format_cds_rows": (ctypes.c_int64, [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
+    "pfa_format_cds_rows": (ctypes.c_int64, [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
                                              _vp, ctypes.c_uint64, _vp]),
     "pfa_format_double": (ctypes.c_int, [ctypes.c_double, _vp]),
     "pfa_classify_codon_mask": (ctypes.c_uint32, [ctypes.c_uint64]),
@@ -157,7 +160,7 @@ _PROTOTYPES = {
     "pfa_ingest_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "pfa_ingest_names": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     "pfa_ingest_close": (None, [_vp]),
-    "pfa_format_rows_indexed": (ctypes.c_int64, [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "pfa_format_rows_indexed": (ctypes.c_int64, [_vp, _vp, _vp, _vp, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                  ctypes.c_int, ctypes.c_int, _vp, ctypes.c_uint64, _vp]),
     "pfa_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "pfa_host_free": (ctypes.c_int, [_vp]),
@@ -193,6 +196,18 @@ def load():
         raise PfaLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m polyfasta_amd._build` "
             "(hipcc, gfx950).  polyfasta_amd has no CPU fallback.")
+    want = None
+    if not os.environ.get("PFA_LIB"):
+        # the library must have been compiled from THESE sources (contents, not modification times): a tree whose
+        # sources changed under an old library rebuilds it when hipcc is there, and refuses otherwise
+        from . import _build
+        want = _build.source_hash()
+        if want is not None and _build.built_id() != want:
+            try:
+                _build.build()
+            except Exception as exc:
+                raise PfaLibraryError(f"{LIB_PATH} was built from other sources than this tree's (build id {_build.built_id()}, "
+                                      f"sources {want}) and cannot be rebuilt here: {exc}") from exc
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as exc:  # pragma: no cover
@@ -203,6 +218,10 @@ def load():
         fn.argtypes = argtypes
     if lib.pfa_abi_version() != PFA_ABI_VERSION:
         raise PfaLibraryError("libpfa_hip.so ABI version mismatch; rebuild it")
+    if not os.environ.get("PFA_LIB") and want is not None and lib.pfa_build_id().decode() != want:
+        # (rebuilt just now, but this process had the old file mapped already: python -m polyfasta_amd loads it early)
+        raise PfaLibraryError(f"{LIB_PATH} has been rebuilt from this tree's sources; an older build was already loaded "
+                              "in this process: run the command again")
     _lib = lib
     return lib
 

@@ -216,11 +216,13 @@ def classify_codon_sets_on_device(codon_sets):
 def getvarCDSsites(d, seqlen):
     """(synonymous-site count, S positions, N positions, nstops, missingcodpos).
     Position lists are ascending (the reference's within-codon order differs;
-    only float summation order could depend on it)."""
+    only float summation order could depend on it).  The count is the reference's own
+    column-by-column floating-point accumulation (PolyFastA.py:307), replayed on the host
+    from the codon sets the card returns per column (stats.syn_sites_replay)."""
     m = fasta.matrix_from_dict(d, seqlen)
     if m.shape[0] == 0 or seqlen == 0:
         return 0.0, [], [], 0, 0
-    out = scan_matrix(m, cds=True, want_sn=True)
+    out = scan_matrix(m, cds=True, want_sn=True, exact_syn=True)
     r = out.results[0]
-    return (stats.syn_sites_from_bins(out.syn_num[0]), [int(p) for p in out.syn_positions(0)],
+    return (float(out.sites_s[0]), [int(p) for p in out.syn_positions(0)],
             [int(p) for p in out.non_positions(0)], int(r["nstops"]), 3 * int(r["missing_cols"]))

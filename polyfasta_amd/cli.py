@@ -53,11 +53,12 @@ def format_plain_row(name, pop, n_rows, seqlen, res, jc):
     return f"{name},{seqlen},{pop},{n_rows},{p[0]},{p[1]},{p[2]},{p[3]}"
 
 
-def format_cds_row(name, pop, n_rows, seqlen, res, syn_num, jc):
+def format_cds_row(name, pop, n_rows, seqlen, res, syn_num, jc, sites_s=None):
     """One coding CSV row (PolyFastA.py:151-180), including the reference's
-    mis-ordered no-variation row (:160-162)."""
+    mis-ordered no-variation row (:160-162).  `sites_s`: the synonymous-site count as the reference
+    accumulates it, for a unit on a rounding tie (scan.resolve_syn_ties); else it comes from the bins."""
     r = _fields(res)
-    ssites = stats.syn_sites_from_bins(syn_num)
+    ssites = stats.syn_sites_from_bins(syn_num) if sites_s is None or sites_s != sites_s else float(sites_s)
     nsites = (seqlen - 3 * r[_MISSING]) - ssites
     if r[_SEG] == 0:
         return f"{name},{round(ssites, 2)},{round(nsites, 2)},{pop},{n_rows},{NO_VAR},{NO_VAR},{0}"
@@ -200,7 +201,8 @@ def _attach(pending, out, done, want_sfs=False):
             sfs = None
             if want_sfs and recs[unit][_BAD] == 0:
                 sfs = out.sfs(unit).tolist()
-            done.append((fidx, "unit", name, pop, n_rows, seqlen, recs[unit], syn, sfs))
+            done.append((fidx, "unit", name, pop, n_rows, seqlen, recs[unit], syn, sfs,
+                         None if out.sites_s is None else float(out.sites_s[unit])))
         else:
             done.append(ev)
 
@@ -210,7 +212,7 @@ def text_alignment_units(data, path, args, keys):
     from the reference's own reading of it (`fasta.read_text_alignment`): every distinct non-ASCII character gets a byte value of
     its own — the scan only asks whether two rows hold the same symbol and whether a symbol is exactly A, C, G or T — and
     the matrix is scanned on the card as one small batch.  Returns (units, lines): units as (key index or PFA_NO_KEY,
-    n_rows, n_sites, record, syn row, sfs list), lines as (sub-order, kind, text); or None when the file holds more than
+    n_rows, n_sites, record, syn row, sfs list, sites_S override or None), lines as (sub-order, kind, text); or None when the file holds more than
     128 distinct non-ASCII characters or no sites."""
     from ._lib import PFA_NO_KEY
     name = path.split("/")[-1]
@@ -247,7 +249,8 @@ def text_alignment_units(data, path, args, keys):
         for i, (j, n_rows) in enumerate(heads):
             bad = int(out.results[i]["sfs_bad"]) != 0
             units.append((j, n_rows, seqlen, out.results[i], None if out.syn_num is None else out.syn_num[i],
-                          None if (bad or not args.sfs) else out.sfs(i).tolist()))
+                          None if (bad or not args.sfs) else out.sfs(i).tolist(),
+                          None if out.sites_s is None else float(out.sites_s[i])))
     return units, lines
 
 
@@ -275,8 +278,8 @@ def process_pipe(indexed_paths, args):
                 name = path.split("/")[-1]
                 items = [(sub, 0, (fidx, kind, line)) for sub, kind, line in got[1]]
                 items += [(0 if j == PFA_NO_KEY else 1 + j, 1,
-                           (fidx, "unit", name, "NA" if j == PFA_NO_KEY else keys[j], n_rows, seqlen, tuple(rec.tolist()), syn, sfs))
-                          for j, n_rows, seqlen, rec, syn, sfs in got[0]]
+                           (fidx, "unit", name, "NA" if j == PFA_NO_KEY else keys[j], n_rows, seqlen, tuple(rec.tolist()), syn, sfs, ssx))
+                          for j, n_rows, seqlen, rec, syn, sfs, ssx in got[0]]
                 items.sort(key=lambda t: t[:2])
                 done.extend(t[2] for t in items)
                 continue
@@ -346,8 +349,8 @@ def _sample_size_constants(nrows):
 
 def format_cds_rows_native(units, jc):
     """The coding rows of many units in one call (csrc/pfa_format.cpp).  `units`: sequences
-    (name, pop, n_rows, seqlen, record tuple, syn_num row).  Returns the text block, or None when
-    some row needs the Python path."""
+    (name, pop, n_rows, seqlen, record tuple, syn_num row, sites_S override or None).  Returns the text
+    block, or None when some row needs the Python path."""
     import ctypes
     from . import _lib
     from ._lib import RESULT_DTYPE
@@ -356,13 +359,14 @@ def format_cds_rows_native(units, jc):
     mids, moff = _blob([f",{u[1]},{u[2]}," for u in units])
     rec = np.array([u[4] for u in units], dtype=RESULT_DTYPE)
     syn = np.ascontiguousarray(np.stack([np.asarray(u[5], dtype=np.uint32) for u in units]))
+    ssx = np.array([np.nan if len(u) < 7 or u[6] is None else u[6] for u in units], dtype=np.float64)
     nrows = np.fromiter((u[2] for u in units), dtype=np.uint32, count=n)
     seqlen = np.fromiter((u[3] for u in units), dtype=np.uint32, count=n)
     a1, e1, e2 = _sample_size_constants(nrows)
     out = np.empty(len(names) + len(mids) + 320 * n + 16, dtype=np.uint8)
     bad = ctypes.c_int64(-1)
     got = _lib.load().pfa_format_cds_rows(names, _lib.ptr(noff), mids, _lib.ptr(moff), n, _lib.ptr(rec), _lib.ptr(syn),
-                                          _lib.ptr(nrows), _lib.ptr(seqlen), _lib.ptr(a1), _lib.ptr(e1), _lib.ptr(e2),
+                                          _lib.ptr(ssx), _lib.ptr(nrows), _lib.ptr(seqlen), _lib.ptr(a1), _lib.ptr(e1), _lib.ptr(e2),
                                           int(bool(jc)), _lib.ptr(out), len(out), ctypes.byref(bad))
     if got < 0:
         if bad.value >= 0:
@@ -399,7 +403,7 @@ def emit(events, sink, cds, jc, sfs=False):
                 if not cds:
                     block = format_plain_rows_native([(e[2], e[3], e[4], e[5], _fields(e[6])) for e in run], jc)
                 elif all(e[7] is not None for e in run):
-                    block = format_cds_rows_native([(e[2], e[3], e[4], e[5], _fields(e[6]), e[7]) for e in run], jc)
+                    block = format_cds_rows_native([(e[2], e[3], e[4], e[5], _fields(e[6]), e[7], e[9] if len(e) > 9 else None) for e in run], jc)
             if block is not None and sink.bulk_ok() and not sfs:
                 sink.rows(block)
             else:
@@ -407,7 +411,7 @@ def emit(events, sink, cds, jc, sfs=False):
                 for k, e in enumerate(run):
                     name, pop, n_rows, seqlen, res, syn = e[2:8]
                     text = rows[k] if rows is not None else (
-                        format_cds_row(name, pop, n_rows, seqlen, res, syn, jc) if cds
+                        format_cds_row(name, pop, n_rows, seqlen, res, syn, jc, e[9] if len(e) > 9 else None) if cds
                         else format_plain_row(name, pop, n_rows, seqlen, res, jc))
                     if sfs:
                         text += "," + _sfs_text(e[8])
@@ -425,8 +429,10 @@ META_DTYPE = np.dtype([("fidx", "<u4"), ("key", "<u4"), ("n_rows", "<u4"), ("n_s
 
 
 class RowBlock:
-    def __init__(self, meta, rec, syn=None, sfs=None, specials=None, io_error=None):
+    def __init__(self, meta, rec, syn=None, sfs=None, specials=None, io_error=None, ssx=None):
         self.meta, self.rec, self.syn = meta, rec, syn
+        # coding rows: NaN, or the synonymous-site count of a unit on a rounding tie as the reference accumulates it (scan.resolve_syn_ties)
+        self.ssx = ssx if ssx is not None or syn is None else np.full(len(meta), np.nan, dtype=np.float64)
         self.sfs = sfs                    # per unit: list of bins, or None (--sfs only)
         self.specials = specials or []    # (fidx, sub, kind, text); sub orders the lines of one file
         self.io_error = io_error          # smallest index of a file that could not be read (the job dies THERE, PolyFastA.py:239), or None
@@ -444,7 +450,11 @@ class RowBlock:
         sfs = None
         if any(b.sfs is not None for b in blocks):
             sfs = [x for b in blocks for x in (b.sfs if b.sfs is not None else [None] * len(b.meta))]
-        return RowBlock(meta, rec, syn, sfs, [x for b in blocks for x in b.specials])
+        ssx = None
+        if coding:
+            ssx = (np.concatenate([b.ssx if b.ssx is not None else np.full(len(b.meta), np.nan) for b in blocks])
+                   if blocks else np.zeros(0, dtype=np.float64))
+        return RowBlock(meta, rec, syn, sfs, [x for b in blocks for x in b.specials], ssx=ssx)
 
     def sorted(self):
         """file order, then population order as typed (PolyFastA.py:104, :124)"""
@@ -454,7 +464,8 @@ class RowBlock:
         if (order == np.arange(len(order))).all():
             return self
         return RowBlock(self.meta[order], self.rec[order], None if self.syn is None else self.syn[order],
-                        None if self.sfs is None else [self.sfs[i] for i in order.tolist()], self.specials)
+                        None if self.sfs is None else [self.sfs[i] for i in order.tolist()], self.specials,
+                        ssx=None if self.ssx is None else self.ssx[order])
 
     def split_below(self, fidx_end):
         """(rows and special lines of files < fidx_end, the rest); self is sorted"""
@@ -462,7 +473,7 @@ class RowBlock:
         lo = [x for x in self.specials if x[0] < fidx_end]
         hi = [x for x in self.specials if x[0] >= fidx_end]
         part = lambda a, b: RowBlock(self.meta[a:b], self.rec[a:b], None if self.syn is None else self.syn[a:b],   # noqa: E731
-                                     None if self.sfs is None else self.sfs[a:b], None)
+                                     None if self.sfs is None else self.sfs[a:b], None, ssx=None if self.ssx is None else self.ssx[a:b])
         first, rest = part(0, k), part(k, len(self.meta))
         first.specials, rest.specials = lo, hi
         return first, rest
@@ -470,15 +481,16 @@ class RowBlock:
     def to_bytes(self):
         import pickle
         return pickle.dumps((self.meta.tobytes(), self.rec.tobytes(), None if self.syn is None else self.syn.tobytes(),
-                             self.sfs, self.specials), protocol=pickle.HIGHEST_PROTOCOL)
+                             self.sfs, self.specials, None if self.ssx is None else self.ssx.tobytes()), protocol=pickle.HIGHEST_PROTOCOL)
 
     @staticmethod
     def from_bytes(blob):
         import pickle
         from ._lib import PFA_SYN_BINS, RESULT_DTYPE
-        meta, rec, syn, sfs, specials = pickle.loads(blob)
+        meta, rec, syn, sfs, specials, ssx = pickle.loads(blob)
         return RowBlock(np.frombuffer(meta, dtype=META_DTYPE).copy(), np.frombuffer(rec, dtype=RESULT_DTYPE).copy(),
-                        None if syn is None else np.frombuffer(syn, dtype=np.uint32).reshape(-1, PFA_SYN_BINS).copy(), sfs, specials)
+                        None if syn is None else np.frombuffer(syn, dtype=np.uint32).reshape(-1, PFA_SYN_BINS).copy(), sfs, specials,
+                        ssx=None if ssx is None else np.frombuffer(ssx, dtype=np.float64).copy())
 
 
 def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
@@ -540,6 +552,9 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
                         specials.append((fidx, 1 + j, "comment", f"# Pop {keys[j]} string was not found in fasta headers."))
         if bad.any():
             keep = ~bad[b.unit_file]
+    ssx = None
+    if syn is not None:
+        ssx = b.sites_s if b.sites_s is not None else np.full(nu, np.nan, dtype=np.float64)
     sfs = None
     if args.sfs and nu:
         off = b.sfs_offsets().tolist()
@@ -549,6 +564,7 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
     if keep is not None:
         meta, res = meta[keep], res[keep]
         syn = None if syn is None else syn[keep]
+        ssx = None if ssx is None else ssx[keep]
         sfs = None if sfs is None else [x for x, k in zip(sfs, keep.tolist()) if k]
     if extra:
         from ._lib import PFA_SYN_BINS
@@ -560,9 +576,11 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
         if args.cds:
             more = np.array([u[5] for u in extra], dtype=np.uint32).reshape(-1, PFA_SYN_BINS)
             syn = more if syn is None else np.concatenate([syn, more])
+            more_x = np.array([np.nan if u[7] is None else u[7] for u in extra], dtype=np.float64)
+            ssx = more_x if ssx is None else np.concatenate([ssx, more_x])
         if args.sfs:
             sfs = (sfs or []) + [u[6] for u in extra]
-    return RowBlock(meta, res, syn, sfs, specials, io_error)
+    return RowBlock(meta, res, syn, sfs, specials, io_error, ssx=ssx)
 
 
 def raise_unreadable(path):
@@ -583,7 +601,8 @@ def block_events(blk, paths, keys):
         pop = "NA" if key == PFA_NO_KEY else keys[key]
         items.append((fidx, 0 if key == PFA_NO_KEY else 1 + key, 1,
                       (fidx, "unit", paths[fidx].split("/")[-1], pop, n_rows, n_sites, rec[i],
-                       None if blk.syn is None else blk.syn[i], None if blk.sfs is None else blk.sfs[i])))
+                       None if blk.syn is None else blk.syn[i], None if blk.sfs is None else blk.sfs[i],
+                       None if blk.ssx is None else float(blk.ssx[i]))))
     for fidx, sub, kind, text in blk.specials:
         items.append((fidx, sub, 0, (fidx, kind, text)))
     items.sort(key=lambda t: t[:3])
@@ -602,11 +621,12 @@ def format_block_native(blk, table, coding, jc):
     a1, e1, e2 = _sample_size_constants(nrows)
     rec = np.ascontiguousarray(blk.rec)
     syn = np.ascontiguousarray(blk.syn) if coding else None
+    ssx = np.ascontiguousarray(blk.ssx, dtype=np.float64) if coding and blk.ssx is not None else None
     out = np.empty((448 if coding else 192) * n + 512 + table.row_bytes(fidx), dtype=np.uint8)
     bad = ctypes.c_int64(-1)
     got = _lib.load().pfa_format_rows_indexed(_lib.ptr(table.names_blob), _lib.ptr(table.names_off), _lib.ptr(table.keys_blob),
                                               _lib.ptr(table.keys_off), n, _lib.ptr(fidx), _lib.ptr(key), _lib.ptr(nrows),
-                                              _lib.ptr(nsites), _lib.ptr(rec), _lib.ptr(syn), _lib.ptr(a1), _lib.ptr(e1), _lib.ptr(e2),
+                                              _lib.ptr(nsites), _lib.ptr(rec), _lib.ptr(syn), _lib.ptr(ssx), _lib.ptr(a1), _lib.ptr(e1), _lib.ptr(e2),
                                               int(bool(jc)), int(bool(coding)), _lib.ptr(out), len(out), ctypes.byref(bad))
     if got < 0:
         if bad.value >= 0:
@@ -648,7 +668,7 @@ def text_runs(blk, table, args):
     cuts = np.flatnonzero(np.diff(fidx) > 1) + 1
     out = []
     for a, b in zip(np.concatenate(([0], cuts)).tolist(), np.concatenate((cuts, [len(fidx)])).tolist()):
-        part = RowBlock(blk.meta[a:b], blk.rec[a:b], None if blk.syn is None else blk.syn[a:b])
+        part = RowBlock(blk.meta[a:b], blk.rec[a:b], None if blk.syn is None else blk.syn[a:b], ssx=None if blk.ssx is None else blk.ssx[a:b])
         text = format_block_native(part, table, args.cds, args.jc)
         if text is None:
             return None

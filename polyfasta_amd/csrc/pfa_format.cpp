@@ -167,8 +167,18 @@ int64_t pfa_format_plain_rows(const char* prefix_blob, const uint64_t* prefix_of
   return (int64_t)w;
 }
 
+// synonymous sites of a row: sum over k of bin[k] / (3 k), ascending k (PolyFastA.py:307) — or the caller's replay of the
+// reference's own accumulation (a row on a two-decimal rounding tie, pfa_plan_codon_sets)
+static double syn_sites(const uint32_t* bins, double given) {
+  if (!std::isnan(given)) return given;
+  double s = 0.0;
+  for (uint32_t k = 1; k < PFA_SYN_BINS; ++k)
+    if (bins[k]) s += (double)bins[k] / (3.0 * (double)k);
+  return s;
+}
+
 int64_t pfa_format_cds_rows(const char* name_blob, const uint64_t* name_off, const char* mid_blob, const uint64_t* mid_off,
-                            uint32_t n, const pfa_result* res, const uint32_t* syn_num, const uint32_t* n_rows,
+                            uint32_t n, const pfa_result* res, const uint32_t* syn_num, const double* sites_s, const uint32_t* n_rows,
                             const uint32_t* seqlen, const double* a1, const double* e1, const double* e2, int jc,
                             char* out, uint64_t cap, int64_t* bad_row) {
   if (bad_row) *bad_row = -1;
@@ -180,11 +190,8 @@ int64_t pfa_format_cds_rows(const char* name_blob, const uint64_t* name_off, con
   for (uint32_t i = 0; i < n; ++i) {
     const uint64_t nlen = name_off[i + 1] - name_off[i], mlen = mid_off[i + 1] - mid_off[i];
     if (w + nlen + mlen + 320u > cap) { pfa::set_error("pfa_format_cds_rows: output capacity %llu too small", (unsigned long long)cap); return PFA_ERR_ARG; }
-    // synonymous sites: sum over k of bin[k] / (3 k), ascending k (PolyFastA.py:307); the rest are non-synonymous (:154)
-    double ssites = 0.0;
-    const uint32_t* bins = syn_num + (uint64_t)i * PFA_SYN_BINS;
-    for (uint32_t k = 1; k < PFA_SYN_BINS; ++k)
-      if (bins[k]) ssites += (double)bins[k] / (3.0 * (double)k);
+    // the synonymous sites; the rest are non-synonymous (PolyFastA.py:154)
+    const double ssites = syn_sites(syn_num + (uint64_t)i * PFA_SYN_BINS, sites_s ? sites_s[i] : NAN);
     const double nsites = (double)((long long)seqlen[i] - 3ll * (long long)res[i].missing_cols) - ssites;
     memcpy(out + w, name_blob + name_off[i], nlen);       // "file,"
     w += nlen;
@@ -224,8 +231,8 @@ int64_t pfa_format_cds_rows(const char* name_blob, const uint64_t* name_off, con
 
 int64_t pfa_format_rows_indexed(const char* names_blob, const uint64_t* names_off, const char* keys_blob, const uint64_t* keys_off,
                                 uint32_t n, const uint32_t* file_idx, const uint32_t* key, const uint32_t* n_rows, const uint32_t* n_sites,
-                                const pfa_result* res, const uint32_t* syn_num, const double* a1, const double* e1, const double* e2,
-                                int jc, int coding, char* out, uint64_t cap, int64_t* bad_row) {
+                                const pfa_result* res, const uint32_t* syn_num, const double* sites_s, const double* a1, const double* e1,
+                                const double* e2, int jc, int coding, char* out, uint64_t cap, int64_t* bad_row) {
   if (bad_row) *bad_row = -1;
   if (n && (!names_blob || !names_off || !file_idx || !key || !n_rows || !n_sites || !res || !a1 || !e1 || !e2 || !out || (coding && !syn_num))) {
     pfa::set_error("pfa_format_rows_indexed: NULL argument");
@@ -264,10 +271,7 @@ int64_t pfa_format_rows_indexed(const char* names_blob, const uint64_t* names_of
       continue;
     }
     // file,sites_S,sites_N,pop,N,... (PolyFastA.py:151-180; the same arithmetic as pfa_format_cds_rows)
-    double ssites = 0.0;
-    const uint32_t* bins = syn_num + (uint64_t)i * PFA_SYN_BINS;
-    for (uint32_t k = 1; k < PFA_SYN_BINS; ++k)
-      if (bins[k]) ssites += (double)bins[k] / (3.0 * (double)k);
+    const double ssites = syn_sites(syn_num + (uint64_t)i * PFA_SYN_BINS, sites_s ? sites_s[i] : NAN);
     const double nsites = (double)((long long)n_sites[i] - 3ll * (long long)res[i].missing_cols) - ssites;
     w += pfa::repr_double(py_round2(ssites), out + w);
     out[w++] = ',';

@@ -93,6 +93,30 @@ __global__ void __launch_bounds__(256) sum_replicas_kernel(unsigned long long* s
   signal_host(flag, ticket);
 }
 
+// The distinct clean codons of every codon column of ONE unit (pfa_plan_codon_sets; PolyFastA.py:291, :301): lane = codon
+// column, so the 64 lanes of a wavefront read 192 consecutive bytes of a row; blockIdx.y = a block of `rows_per_block` rows
+// (units with many rows: the blocks OR their sets together).  A re-scan of the rare unit whose synonymous-site count lands on
+// a rounding tie — a few units in a thousand — not a bandwidth kernel.
+__global__ void __launch_bounds__(64) codon_sets_kernel(const uint8_t* __restrict__ bases, const pfa_desc* __restrict__ descs,
+                                                        const uint32_t* __restrict__ row_idx, uint32_t unit, uint32_t rows_per_block,
+                                                        unsigned long long* __restrict__ sets) {
+  const pfa_desc D = descs[unit];
+  const uint32_t col = blockIdx.x * 64u + threadIdx.x;
+  if ((uint64_t)col * 3u + 2u >= D.n_sites) return;     // beyond the last whole codon (a partial one holds no clean codon, :301)
+  const uint32_t r0 = blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < D.n_rows ? r0 + rows_per_block : D.n_rows;
+  const uint8_t* const mat = bases + D.base_off + (uint64_t)col * 3u;
+  const uint32_t* const rows = D.row_idx_off != PFA_NO_ROW_IDX ? row_idx + D.row_idx_off : nullptr;
+  unsigned long long m = 0ull;
+#pragma unroll 4
+  for (uint32_t r = r0; r < r1; ++r) {
+    const uint8_t* const p = mat + (uint64_t)(rows ? rows[r] : r) * D.row_stride;
+    const uint32_t x0 = p[0], x1 = p[1], x2 = p[2];
+    if (base_clean(x0) && base_clean(x1) && base_clean(x2)) m |= 1ull << (base_code(x0) * 16u + base_code(x1) * 4u + base_code(x2));
+  }
+  if (gridDim.y == 1u) sets[col] = m;
+  else if (m) atomicOr(&sets[col], m);
+}
+
 static constexpr uint32_t kLdsPerCu = 160u * 1024u;
 static constexpr uint32_t kTallSlots = 64u;     // its count-table slots per tile (measured: 64 6.03, 96 5.68 TB/s at N = 100)
 static constexpr int kEventRing = 64;
@@ -185,6 +209,8 @@ struct pfa_plan {
   uint64_t sfs_words = 0;
   uint64_t n_bases_bytes = 0;
   std::vector<pfa::Bucket> buckets;   // largest first
+  std::vector<pfa_desc> h_descs;      // the caller's table (pfa_plan_codon_sets sizes its re-scan of one unit by it)
+  const uint8_t* last_bases = nullptr; // the matrices of the last run
   pfa_desc* d_descs = nullptr;
   uint32_t* d_row_idx = nullptr;
   uint32_t* d_unit_ids = nullptr;
@@ -217,6 +243,11 @@ struct pfa_plan {
 extern "C" {
 
 int pfa_abi_version(void) { return PFA_ABI_VERSION; }
+
+// "PFA_BUILD_ID=<16 hex digits>": the translation unit polyfasta_amd/_build.py generates from the hash of the sources (the
+// marker lets the host side read the id out of the file without loading it)
+extern "C" const char pfa_build_id_string[];
+const char* pfa_build_id(void) { return pfa_build_id_string + 13; }
 
 const char* pfa_last_error(void) { return pfa::g_err; }
 
@@ -310,6 +341,8 @@ void pfa_prewarm(int device) {
     g_prewarm = nullptr;
   }
 }
+
+void pfa_prewarm_join(void) { join_prewarm(); }
 
 int pfa_init(int device) {
   join_prewarm();
@@ -638,6 +671,7 @@ int pfa_plan_create(const pfa_desc* descs, uint32_t n_desc, const uint32_t* row_
     p->sfs_words = sfs_words;
     p->n_tiles_total = (uint32_t)tiles_total;
     p->n_bases_bytes = n_bases_bytes;
+    p->h_descs.assign(descs, descs + n_desc);
     p->timing = getenv("PFA_PLAN_TIMING") != nullptr;
 
     // ---- buckets.  A plan too small to give every CU a few wavefronts takes narrower tiles
@@ -746,6 +780,7 @@ int pfa_plan_run(pfa_plan* p, const uint8_t* d_bases, int variant) {
   p->slab_clean = false;
   p->host_valid = false;
   p->summed = p->replicas == 1u;
+  p->last_bases = d_bases;
   if (p->d_syn_bm) {  // S / N bitmaps are built with atomicOr: clear them every run
     const size_t nb = std::max<size_t>(1, p->n_tiles_total) * 4u * sizeof(uint64_t);
     PFA_HIP(hipMemsetAsync(p->d_syn_bm, 0, nb, st));
@@ -892,6 +927,43 @@ int pfa_plan_results_dev(pfa_plan* p, void** d_results, size_t* bytes) {
   *d_results = p->d_results;
   *bytes = (size_t)p->n_desc * sizeof(pfa_result);
   return PFA_OK;
+}
+
+int pfa_plan_codon_sets(pfa_plan* p, const uint8_t* d_bases, uint32_t unit, uint64_t* sets_out, uint64_t cap) {
+  PFA_NEED_INIT();
+  if (!p) { pfa::set_error("pfa_plan_codon_sets: plan is NULL"); return PFA_ERR_ARG; }
+  if (unit >= p->n_desc) { pfa::set_error("pfa_plan_codon_sets: unit %u of %u", unit, p->n_desc); return PFA_ERR_ARG; }
+  if (!d_bases) d_bases = p->last_bases;
+  if (!d_bases) { pfa::set_error("pfa_plan_codon_sets: no matrices (the plan has not been run and d_bases is NULL)"); return PFA_ERR_ARG; }
+  const pfa_desc& d = p->h_descs[unit];
+  const uint64_t n_cols = ((uint64_t)d.n_sites + 2u) / 3u;
+  if (n_cols == 0) return PFA_OK;
+  if (!sets_out || cap < n_cols) { pfa::set_error("pfa_plan_codon_sets: %llu words needed, %llu given", (unsigned long long)n_cols, (unsigned long long)cap); return PFA_ERR_ARG; }
+  memset(sets_out, 0, n_cols * sizeof(uint64_t));
+  if (d.n_rows == 0 || d.n_sites < 3u) return PFA_OK;
+  hipStream_t st = pfa::ctx().stream;
+  unsigned long long* d_sets = nullptr;
+  size_t cap_sets = 0;
+  PFA_HIP(pfa::g_pool.take(false, n_cols * sizeof(uint64_t), (void**)&d_sets, &cap_sets));
+  // rows shared out over blockIdx.y once a unit has more than a few thousand (the blocks OR into a cleared array)
+  const uint32_t rows_per_block = 4096u;
+  const uint32_t ny = (d.n_rows + rows_per_block - 1u) / rows_per_block;
+  int rc = PFA_OK;
+  hipError_t e = hipMemsetAsync(d_sets, 0, n_cols * sizeof(uint64_t), st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(pfa::codon_sets_kernel, dim3((unsigned)((d.n_sites / 3u + 63u) / 64u), ny, 1), dim3(64), 0, st,
+                       d_bases, p->d_descs, p->d_row_idx, unit, rows_per_block, d_sets);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(sets_out, d_sets, n_cols * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    pfa::set_error("pfa_plan_codon_sets: %s", hipGetErrorString(e));
+    rc = PFA_ERR_HIP;
+    (void)hipStreamSynchronize(st);
+  }
+  pfa::g_pool.give(false, d_sets, cap_sets);
+  return rc;
 }
 
 uint32_t pfa_plan_n_tiles(const pfa_plan* p) { return p ? p->n_tiles_total : 0u; }

@@ -46,11 +46,14 @@ class IngestBatch:
         self._bad_ptr = c.bad_bytes
         self._plan = c.plan
         self.bad = None
+        self.sites_s = None
 
     def fetch(self, coding, want_sfs=False):
         """Wait for the scan; -> (records RESULT_DTYPE[n_units], syn_num uint32[n_units, 65] or
         None, folded SFS (flat, unit i at sfs_off[i]) or None).  Also reads the per-file flags
-        for bytes >= 0x80 in sequence lines (`self.bad`)."""
+        for bytes >= 0x80 in sequence lines (`self.bad`) and, for coding batches, re-scans the units whose
+        synonymous-site count sits on a rounding tie while their matrices are still on the card
+        (`self.sites_s`: NaN or the reference's own accumulation, scan.resolve_syn_ties)."""
         lib = _lib.load()
         nu = self.n_units
         res = np.zeros(nu, dtype=RESULT_DTYPE)
@@ -63,6 +66,9 @@ class IngestBatch:
         else:
             _lib.check(lib.pfa_sync())
         self.bad = _arr(self._bad_ptr, self.n_files, np.uint32)
+        if syn is not None and self._plan:
+            from .scan import resolve_syn_ties
+            self.sites_s = resolve_syn_ties(self._plan, syn, self.n_sites[self.unit_file])
         return res, syn, sfs
 
     def sfs_offsets(self):

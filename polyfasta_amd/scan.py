@@ -164,12 +164,42 @@ class Batch:
         return bases, finalize_layout(descs, row_idx, len(bases))
 
 
+def codon_sets(plan_handle, unit: int, n_sites: int, d_bases=None) -> np.ndarray:
+    """The set of distinct clean codons of every codon column of one unit of a plan (pfa_plan_codon_sets: a re-scan of
+    that unit on the card; `cods` of getvarCDSsites after its regex filter, PolyFastA.py:291, :301): uint64[ceil(L / 3)].
+    `d_bases` None: the matrices of the plan's last run."""
+    out = np.zeros((int(n_sites) + 2) // 3, dtype=np.uint64)
+    p = None if d_bases is None else (d_bases.ptr if isinstance(d_bases, DeviceBuffer) else ctypes.c_void_p(int(d_bases)))
+    _lib.check(_lib.load().pfa_plan_codon_sets(plan_handle, p, int(unit), _lib.ptr(out) if len(out) else None, len(out)))
+    return out
+
+
+def resolve_syn_ties(plan_handle, syn_num, n_sites, d_bases=None, every=None):
+    """Per unit NaN, or — for a unit whose synonymous-site count sits on a two-decimal rounding tie — that count as the
+    reference itself accumulates it, column by column in floating point (PolyFastA.py:307), replayed from the unit's codon
+    sets (stats.syn_sites_replay).  A handful of units in a thousand; everything else prints the same digits either way.
+    Call it while the matrices of the plan's run are still on the card.  `every`: bool per unit — replay these whatever
+    their bins say (the API mirror returns the reference's count_syn itself)."""
+    from . import stats
+    n_sites = np.asarray(n_sites)
+    out = np.full(len(n_sites), np.nan, dtype=np.float64)
+    if syn_num is None or len(out) == 0:
+        return out
+    pick = stats.syn_tie_candidates(syn_num, n_sites)
+    if every is not None:
+        pick = pick | np.asarray(every, dtype=bool)
+    for i in np.flatnonzero(pick).tolist():
+        out[i] = stats.syn_sites_replay(codon_sets(plan_handle, i, int(n_sites[i]), d_bases))
+    return out
+
+
 @dataclass
 class ScanOutput:
     table: UnitTable
     results: np.ndarray            # RESULT_DTYPE[n_units]
     sfs_flat: np.ndarray           # uint32
     syn_num: np.ndarray = None     # uint32[n_units, 65] (coding plans)
+    sites_s: np.ndarray = None     # float64[n_units]: NaN, or the replayed synonymous-site count of a unit on a rounding tie (scan_batch)
     var_bitmap: np.ndarray = None
     syn_bitmap: np.ndarray = None
     non_bitmap: np.ndarray = None
@@ -261,6 +291,9 @@ class Plan:
                                                   _lib.ptr(vb), _lib.ptr(sb), _lib.ptr(nb)))
         return ScanOutput(table=self.table, results=res, sfs_flat=sfs, syn_num=syn, var_bitmap=vb, syn_bitmap=sb, non_bitmap=nb)
 
+    def codon_sets(self, unit: int, d_bases=None) -> np.ndarray:
+        return codon_sets(self.handle, unit, int(self.table.descs[unit]["n_sites"]), d_bases)
+
     def results_dev(self):
         p = ctypes.c_void_p()
         n = ctypes.c_size_t()
@@ -305,8 +338,9 @@ class Plan:
             pass
 
 
-def scan_batch(batch: Batch, want_pos: bool = False, want_sn: bool = False, variant: int = 0) -> ScanOutput:
-    """Pack, upload, scan, fetch: the one-call path used by the API mirror and the CLI."""
+def scan_batch(batch: Batch, want_pos: bool = False, want_sn: bool = False, variant: int = 0, exact_syn: bool = False) -> ScanOutput:
+    """Pack, upload, scan, fetch: the one-call path used by the API mirror and the CLI.  `exact_syn`: `sites_s` of EVERY
+    coding unit is the reference's own floating-point accumulation (else only of units on a rounding tie)."""
     bases, table = batch.pack()
     if table.n_units == 0:
         raise ValueError("empty batch")
@@ -316,7 +350,12 @@ def scan_batch(batch: Batch, want_pos: bool = False, want_sn: bool = False, vari
         plan = Plan(table, want_pos=want_pos, want_sn=want_sn)
         try:
             plan.run(dev, variant=variant)
-            return plan.fetch()
+            out = plan.fetch()
+            if out.syn_num is not None:
+                coding = (table.descs["flags"] & PFA_FLAG_CDS) != 0
+                out.sites_s = resolve_syn_ties(plan.handle, np.where(coding[:, None], out.syn_num, 0), table.descs["n_sites"],
+                                               every=coding if exact_syn else None)
+            return out
         finally:
             plan.close()
     finally:
@@ -324,7 +363,7 @@ def scan_batch(batch: Batch, want_pos: bool = False, want_sn: bool = False, vari
 
 
 def scan_matrix(matrix: np.ndarray, rows=None, cds: bool = False, want_pos: bool = False,
-                want_sn: bool = False, variant: int = 0) -> ScanOutput:
+                want_sn: bool = False, variant: int = 0, exact_syn: bool = False) -> ScanOutput:
     b = Batch()
     b.add_unit(b.add_matrix(matrix), rows=rows, cds=cds)
-    return scan_batch(b, want_pos=want_pos, want_sn=want_sn, variant=variant)
+    return scan_batch(b, want_pos=want_pos, want_sn=want_sn, variant=variant, exact_syn=exact_syn)

@@ -98,3 +98,74 @@ def syn_sites_from_bins(syn_num) -> float:
         if k:
             total += int(bins[k]) / (3.0 * k)
     return total
+
+
+# ------------------------------------------------------------------ the reference's own accumulation of count_syn
+# `sites_S` / `sites_N` are printed as round(x, 2) of a sum the reference builds column by column in floating point
+# (PolyFastA.py:307: count_syn += sum([syncodfreq(c) for c in cod]) / len(cod); :167, :178).  The exact value of that sum —
+# what the bins give — is a two-decimal tie (....375 = 3/8) whenever a codon column with 8, 16, ... distinct codons puts a
+# factor 8 into its denominator; then the last bits of the reference's accumulation decide the printed digit, and they are
+# reproduced here from the column's codon sets (pfa_plan_codon_sets: a re-scan of that one unit on the card).
+_ALPHA_RANK = (0, 1, 3, 2)      # codon-set bit order is A C T G ((ascii >> 1) & 3); strings sort A C G T
+
+
+def _syn_float_by_codon():
+    """syncodfreq (PolyFastA.py:536-557) as the reference's floats, by codon-set bit: 0, 1/3, 2/3, 1., 4/3"""
+    import numpy as np
+    from . import _lib
+    lib = _lib.load()
+    f = (0.0, 1 / 3, 2 / 3, 1.0, 4 / 3)
+    return np.array([f[lib.pfa_codon_syn_thirds(c)] for c in range(64)], dtype=np.float64)
+
+
+_SYN_FLOAT = None
+
+
+def syn_tie_candidates(syn_num, n_sites):
+    """Units whose synonymous-site count (or its complement, :167) sits on a two-decimal rounding boundary as far as double
+    precision can tell: bool[n_units].  `syn_num`: uint32[n_units, 65]; `n_sites`: alignment length per unit.  The
+    reference's accumulated rounding error is below (columns) x ulp(sum); anything within a generous multiple of that of
+    xxx.xx5 is replayed."""
+    import numpy as np
+    bins = np.asarray(syn_num, dtype=np.float64).reshape(-1, 65)
+    k3 = 3.0 * np.arange(1, 65, dtype=np.float64)
+    x = (bins[:, 1:] / k3).sum(axis=1)
+    y = 100.0 * x
+    d = np.abs(y - np.floor(y) - 0.5)
+    cols = np.asarray(n_sites, dtype=np.float64) / 3.0 + 1.0
+    return d < 1e-6 + 400.0 * cols * np.spacing(np.maximum(x, 1.0))
+
+
+def syn_sites_replay(sets):
+    """count_syn exactly as getvarCDSsites accumulates it (PolyFastA.py:307), from the set of distinct clean codons of every
+    codon column in column order (`sets`: uint64[ceil(L / 3)], 0 = no clean codon: the column adds nothing, :301-305).
+    Per column sum([syncodfreq(c) ...]) / len(...) — Python's left-to-right float sum starting from int 0 — then added
+    to the running total.  Columns with three or more codons are summed in ascending codon order (the reference walks
+    a Python set of strings there: its order, and with it the last bit of such a term, follows the interpreter's hash
+    seed)."""
+    import numpy as np
+    global _SYN_FLOAT
+    if _SYN_FLOAT is None:
+        _SYN_FLOAT = _syn_float_by_codon()
+    F = _SYN_FLOAT
+    s = np.ascontiguousarray(sets, dtype=np.uint64)
+    s = s[s != 0]
+    if len(s) == 0:
+        return 0.0
+    k = np.bitwise_count(s).astype(np.int64)
+    one = np.uint64(1)
+    low = s & (~s + one)                                   # lowest set bit
+    c1 = np.bitwise_count(low - one).astype(np.int64)      # its index
+    rest = s ^ low
+    low2 = rest & (~rest + one)
+    c2 = np.bitwise_count(np.where(rest != 0, low2 - one, np.uint64(0))).astype(np.int64)
+    terms = np.where(k == 1, F[c1], (F[c1] + F[c2]) / 2.0)  # two terms: a + b is the same either way round
+    for i in np.flatnonzero(k >= 3).tolist():
+        m = int(s[i])
+        cods = sorted((c for c in range(64) if (m >> c) & 1),
+                      key=lambda c: (_ALPHA_RANK[c >> 4], _ALPHA_RANK[(c >> 2) & 3], _ALPHA_RANK[c & 3]))
+        t = 0
+        for c in cods:
+            t = t + float(F[c])
+        terms[i] = t / len(cods)
+    return float(np.add.accumulate(terms)[-1])            # sequential: r[i] = r[i-1] + terms[i]

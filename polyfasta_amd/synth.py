@@ -174,6 +174,17 @@ def inject_symbols(matrix: np.ndarray, seed: int, frac: float, alphabet: bytes) 
     return out
 
 
+def plant_codons(matrix: np.ndarray, col: int, codons, rows=None) -> np.ndarray:
+    """Write `codons` (3-letter strings) round robin into codon column `col` (sites 3 col .. 3 col + 2) of the rows `rows`
+    (all rows by default): a column with 8 or 16 distinct codons puts the factor 8 into the denominator of the
+    synonymous-site sum that makes two-decimal rounding ties possible (tests/golden G12)."""
+    out = matrix.copy()
+    rows = np.arange(out.shape[0]) if rows is None else np.asarray(rows)
+    cod = np.array([list(c.encode()) for c in codons], dtype=np.uint8)
+    out[rows, 3 * col:3 * col + 3] = cod[np.arange(len(rows)) % len(cod)]
+    return out
+
+
 def headers_for(n_rows: int, pops: int = 0):
     """``indiv{i}`` like the reference's examples, or ``pop{1+i%pops}_ind{i}``."""
     if pops:

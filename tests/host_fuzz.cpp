@@ -10,6 +10,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <cmath>
 #include <string>
 #include <sys/stat.h>
 #include <vector>
@@ -180,6 +181,8 @@ static void fuzz_rows() {
   {
     std::vector<pfa_result> res(n);
     std::vector<uint32_t> syn((size_t)n * PFA_SYN_BINS), sl(n);
+    std::vector<double> ssx(n);   // optional per-row synonymous-site override: NaN (use the bins) or a value
+    for (uint32_t i = 0; i < n; ++i) ssx[i] = below(3) ? NAN : below(100000) / 8.0;
     std::vector<uint64_t> noff(n + 1, 0), moff(n + 1, 0);
     std::string names, mids;
     for (uint32_t i = 0; i < n; ++i) {
@@ -202,7 +205,7 @@ static void fuzz_rows() {
     char* out2 = (char*)malloc(cap2 ? cap2 : 1);
     int64_t bad2 = -1;
     const int64_t got2 = pfa_format_cds_rows(names.data(), noff.data(), mids.data(), moff.data(), n, res.data(), syn.data(),
-                                             nrows.data(), sl.data(), a1.data(), e1.data(), e2.data(), (int)below(2), out2, cap2, &bad2);
+                                             below(2) ? ssx.data() : nullptr, nrows.data(), sl.data(), a1.data(), e1.data(), e2.data(), (int)below(2), out2, cap2, &bad2);
     if (got2 > (int64_t)cap2) { fprintf(stderr, "cds format wrote %lld > cap %llu\n", (long long)got2, (unsigned long long)cap2); abort(); }
     free(out2);
   }

@@ -263,3 +263,31 @@ def test_many_rows_g10_python_oracle():
             assert C.close(cs, k["count_syn"], 1e-12) and C.sha1_ints(sorted(s)) == k["S_sha1"] and C.sha1_ints(sorted(n)) == k["N_sha1"]
             assert (nstops, missing) == (k["nstops"], k["missing"])
             C.rows_close(orc.result_row(d, c["L"], True, "x.fa", "NA", True), k["row_jc"], rel=1e-10, rel_jc=1e-10)
+
+
+def test_rounding_ties_g12():
+    """G12: alignments whose exact synonymous-site sum is a two-decimal tie, rows frozen from the reference.  The C oracle
+    accumulates count_syn in column order like the reference (pfa_oracle.c: `count_syn += s3 / k`): the same double, the same
+    printed digits, on every case; the Python restatement on the smaller ones."""
+    from polyfasta_amd import synth
+    g12 = C.load("g12_rounding_ties.json")
+    n_py = 0
+    for case in g12["cases"]:
+        g = case["gen"]
+        m = C.g12_matrix(g)
+        hdr = synth.headers_for(g["N"], g.get("pops", 0))
+        for key, k in case["keys"].items():
+            rows = None if key == "NA" else np.array([i for i, h in enumerate(hdr) if key in h], dtype=np.uint32)
+            o = c_oracle.scan(m, rows=rows, cds=True)
+            assert repr(o["count_syn"]) == k["count_syn"], (g, key)
+            n = len(hdr) if rows is None else len(rows)
+            for jc, rk in ((False, "row"), (True, "row_jc")):
+                got = orc.row_from_counts("x.fa", key, n, g["L"], o, True, jc)
+                assert got.split(",")[:3] == k[rk].split(",")[:3] and C.row_matches(got, k[rk], True, jc) is None, (g, key, got, k[rk])
+            if g["N"] <= 64 and k["tie"] and n_py < 6:
+                d = synth.to_dict(hdr, m)
+                grp = d if key == "NA" else {h: s for h, s in d.items() if key in h}
+                got = orc.result_row(grp, g["L"], True, "x.fa", key, False)
+                assert got.split(",")[:3] == k["row"].split(",")[:3], (g, key, got, k["row"])
+                n_py += 1
+    assert n_py == 6

@@ -1,0 +1,140 @@
+"""Two-decimal rounding ties of sites_S / sites_N (PolyFastA.py:307, :167, :178) — the host side, no GPU: the replay of the
+reference's column-order accumulation from per-column codon sets, the tie detector, both formatters, against G12 (rows
+frozen from the reference on alignments whose exact synonymous-site sum is a tie)."""
+import itertools
+
+import numpy as np
+import pytest
+
+from polyfasta_amd import _lib, cli, stats, synth
+from tests import _cases as C
+
+
+@pytest.fixture(scope="module")
+def g12():
+    return C.load("g12_rounding_ties.json")
+
+
+def _units(g12):
+    for case in g12["cases"]:
+        g = case["gen"]
+        m = C.g12_matrix(g)
+        hdr = synth.headers_for(g["N"], g.get("pops", 0))
+        for key, k in case["keys"].items():
+            rows = [i for i, h in enumerate(hdr) if key in h] if key != "NA" else list(range(g["N"]))
+            yield g, key, k, m[rows]
+
+
+def test_fixture_holds_enough_ties_of_every_kind(g12):
+    ties = [(c["gen"], key) for c in g12["cases"] for key, k in c["keys"].items() if k["tie"]]
+    assert len(ties) >= 20
+    gens = [g for g, _ in ties]
+    assert any(g.get("pops") for g in gens) and any(g["N"] >= 200 for g in gens) and any(g["N"] >= 1000 for g in gens)
+    assert any(g["L"] % 3 for g in gens) and any(g.get("inject") for g in gens) and any(not g.get("plant") for g in gens)
+
+
+def test_replay_reproduces_the_references_count_syn_bit_for_bit(g12):
+    """stats.syn_sites_replay on the codon sets of every G12 unit == the reference's count_syn (repr), whenever the
+    reference's own value does not hang on its hash seed; the printed digits always."""
+    n = 0
+    for g, key, k, sub in _units(g12):
+        sets = C.codon_sets_numpy(sub)
+        x = stats.syn_sites_replay(sets)
+        want = float(k["count_syn"])
+        if k["count_syn_order_free"]:
+            assert repr(x) == k["count_syn"], (g, key)
+            n += 1
+        assert round(x, 2) == round(want, 2), (g, key, x, want)
+        assert abs(x - want) <= 1e-9
+    assert n >= 10
+
+
+def test_tie_detector_finds_every_tie_and_little_else(g12):
+    """from the integer bins alone: every G12 tie is flagged; ordinary alignments are not"""
+    bins, L, tie = [], [], []
+    for g, key, k, sub in _units(g12):
+        bins.append(C.syn_bins_numpy(sub))
+        L.append(g["L"])
+        tie.append(k["tie"])
+    got = stats.syn_tie_candidates(np.array(bins), np.array(L))
+    assert got.tolist() == tie
+    p = synth.make_params(50, 0.01)
+    plain = np.array([C.syn_bins_numpy(synth.synth_alignment(5, a, 3000, p, coding=True)) for a in range(40)])
+    assert not stats.syn_tie_candidates(plain, np.full(40, 3000)).any()
+
+
+def test_rows_with_the_replayed_count_are_the_references_text(g12):
+    """cli.format_cds_row and the native formatters, given the replayed count: sites_S / sites_N character for character, the
+    rest of the row within the float tolerances — and WITHOUT it the tie rows print the other digit at least once (the
+    fixture does pin something)."""
+    from oracle import c_oracle
+    units, wants, flipped = [], {False: [], True: []}, 0
+    for g, key, k, sub in _units(g12):
+        o = c_oracle.scan(sub, cds=True)
+        rec = (o["H"], o["H_S"], o["H_N"], o["S"], o["sfs_bad"], o["seg_S"], o["seg_N"], o["nstops"], o["missing_cols"], 0, 0)
+        syn = C.syn_bins_numpy(sub)
+        x = stats.syn_sites_replay(C.codon_sets_numpy(sub))
+        units.append(("x.fa", key, len(sub), g["L"], rec, syn, x if k["tie"] else None))
+        for jc in (False, True):
+            want = k["row_jc" if jc else "row"]
+            wants[jc].append(want)
+            got = cli.format_cds_row("x.fa", key, len(sub), g["L"], rec, syn, jc, x if k["tie"] else None)
+            assert got.split(",")[1:3] == want.split(",")[1:3], (g, key, got, want)
+            assert C.row_matches(got, want, True, jc) is None, (g, key, got, want)
+        if k["tie"] and cli.format_cds_row("x.fa", key, len(sub), g["L"], rec, syn, False).split(",")[1:3] != k["row"].split(",")[1:3]:
+            flipped += 1
+    assert flipped >= 3
+    for jc in (False, True):
+        text = cli.format_cds_rows_native(units, jc)
+        assert text == "".join(cli.format_cds_row(*u[:6], jc, u[6]) + "\n" for u in units)
+        for got, want in zip(text.rstrip("\n").split("\n"), wants[jc]):
+            assert got.split(",")[1:3] == want.split(",")[1:3]
+    # the block formatter (what a directory run prints through) and a block that travels between ranks
+    meta = np.zeros(len(units), dtype=cli.META_DTYPE)
+    meta["fidx"], meta["key"] = np.arange(len(units)), _lib.PFA_NO_KEY
+    meta["n_rows"], meta["n_sites"] = [u[2] for u in units], [u[3] for u in units]
+    blk = cli.RowBlock(meta, np.array([u[4] for u in units], dtype=_lib.RESULT_DTYPE), np.array([u[5] for u in units], dtype=np.uint32),
+                       ssx=np.array([np.nan if u[6] is None else u[6] for u in units]))
+    blk2 = cli.RowBlock.from_bytes(blk.to_bytes())
+    assert np.array_equal(blk2.ssx, blk.ssx, equal_nan=True)
+    both = cli.RowBlock.concat([blk.split_below(7)[1], blk.split_below(7)[0]], True).sorted()
+    assert np.array_equal(both.ssx, blk.ssx, equal_nan=True) and np.array_equal(both.syn, blk.syn)
+    from polyfasta_amd.ingest import NameTable
+    table = NameTable.from_paths([f"d/f{i}.fa" for i in range(len(units))])
+    text = cli.format_block_native(both, table, True, False)
+    for i, (got, want) in enumerate(zip(text.rstrip("\n").split("\n"), wants[False])):
+        assert got.split(",")[1:3] == want.split(",")[1:3] and got.startswith(f"f{i}.fa,")
+
+
+def test_replay_is_pythons_left_to_right_sum():
+    """syn_sites_replay against the reference's loop written out (PolyFastA.py:307) on random codon-set columns, including
+    columns with up to 64 codons, empty columns and runs of stop codons"""
+    rng = np.random.default_rng(12)
+    lib = _lib.load()
+    rank = (0, 1, 3, 2)
+    f = (0, 1 / 3, 2 / 3, 1., 4 / 3)
+    for trial in range(30):
+        n = int(rng.integers(1, 4000))
+        sets = np.zeros(n, dtype=np.uint64)
+        for i in range(n):
+            r = rng.random()
+            k = 0 if r < 0.05 else 1 if r < 0.8 else 2 if r < 0.93 else int(rng.integers(3, 9)) if r < 0.995 else int(rng.integers(9, 65))
+            for c in rng.choice(64, size=k, replace=False).tolist():
+                sets[i] |= np.uint64(1) << np.uint64(c)
+        total = 0.0
+        for s in sets.tolist():
+            cods = sorted((c for c in range(64) if (s >> c) & 1), key=lambda c: (rank[c >> 4], rank[(c >> 2) & 3], rank[c & 3]))
+            if cods:
+                total += sum([f[lib.pfa_codon_syn_thirds(c)] for c in cods]) / len(cods)
+        assert stats.syn_sites_replay(sets) == total
+    assert stats.syn_sites_replay(np.zeros(0, dtype=np.uint64)) == 0.0 and stats.syn_sites_replay(np.zeros(5, dtype=np.uint64)) == 0.0
+
+
+def test_exact_ties_need_a_column_of_eight_codons():
+    """the arithmetic behind the detector: sums of b_k / (3 k) over k <= 7 are never an odd multiple of 1/200"""
+    from fractions import Fraction
+    for ks in itertools.combinations(range(1, 8), 3):
+        for nums in itertools.product(range(0, 40, 7), repeat=3):
+            x = sum(Fraction(b, 3 * k) for b, k in zip(nums, ks))
+            assert (200 * x).denominator != 1 or (200 * x).numerator % 2 == 0
+    assert (200 * (Fraction(2201) + Fraction(9, 24))).numerator % 2 == 1

@@ -1,0 +1,169 @@
+"""Two-decimal rounding ties of sites_S / sites_N on the card (PolyFastA.py:307, :167, :178): the per-column codon sets of
+pfa_plan_codon_sets against numpy, and G12 — rows frozen from the reference on alignments whose exact synonymous-site sum is
+a tie — through the command line, compared AS TEXT."""
+import io
+import os
+import shutil
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from polyfasta_amd import api, cli, scan, stats, synth
+from tests import _cases as C
+
+pytestmark = pytest.mark.gpu
+
+
+def run_cli(argv):
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        rc = cli.main(argv)
+    return rc, buf.getvalue()
+
+
+@pytest.fixture(scope="module")
+def g12():
+    return C.load("g12_rounding_ties.json")
+
+
+def test_codon_sets_match_numpy_on_every_kind_of_unit(gpu):
+    """pfa_plan_codon_sets: units of 1 to 9 000 rows (above 4 096 the rows are shared out over several workgroups that OR
+    their sets), lengths that are not multiples of 3, N / - / lower-case-free IUPAC bytes, stop codons, row-index lists over
+    a larger matrix, a unit that is not the plan's first, matrices passed explicitly and by "the plan's last run"."""
+    rng = np.random.default_rng(5)
+    shapes = [(1, 3), (1, 2), (2, 7), (50, 9000), (50, 9001), (64, 300), (200, 999), (1000, 3000), (9000, 301), (5, 64 * 3 + 1)]
+    b = scan.Batch(stride_align=128)
+    mats, units = [], []
+    for n, L in shapes:
+        m = synth.synth_alignment(77, n, L, synth.make_params(max(n, 2), 0.05), coding=True)[:n]
+        m = synth.inject_symbols(m, n + L, 0.01, b"-NRY")
+        if L >= 300:
+            m = synth.plant_codons(m, 11, ["TAA", "TAG", "TGA", "ATG", "AAA", "CCC", "GGG", "TTT", "ACG"])
+        mid = b.add_matrix(m)
+        b.add_unit(mid, cds=True)
+        mats.append(m)
+        units.append((m, None))
+        if n >= 50:
+            rows = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.uint32)
+            b.add_unit(mid, rows=rows, cds=bool(n % 100))      # (coding or not: the re-scan does not care)
+            units.append((m, rows))
+    bases, table = b.pack()
+    dev = scan.DeviceBuffer(len(bases))
+    try:
+        dev.upload(bases)
+        plan = scan.Plan(table)
+        try:
+            # before any run, with the matrices named
+            for i in (0, 3, len(units) - 1):
+                m, rows = units[i]
+                assert np.array_equal(plan.codon_sets(i, dev), C.codon_sets_numpy(m if rows is None else m[rows])), i
+            with pytest.raises(Exception):
+                plan.codon_sets(0)                              # no run yet, no matrices named
+            plan.run(dev)
+            out = plan.fetch()
+            for i, (m, rows) in enumerate(units):
+                sub = m if rows is None else m[rows]
+                assert np.array_equal(plan.codon_sets(i), C.codon_sets_numpy(sub)), (i, sub.shape)
+                if table.descs[i]["flags"]:
+                    assert np.array_equal(out.syn_num[i], C.syn_bins_numpy(sub)), i
+            with pytest.raises(Exception):
+                plan.codon_sets(len(units))
+        finally:
+            plan.close()
+    finally:
+        dev.free()
+
+
+def _write_dir(root, cases, pops):
+    d = os.path.join(root, "pops" if pops else "plain")
+    os.makedirs(d)
+    names = []
+    for i, case in enumerate(cases):
+        g = case["gen"]
+        if bool(g.get("pops")) != pops:
+            continue
+        name = f"tie{i:02d}.fa"
+        with open(os.path.join(d, name), "w") as fh:
+            fh.write(synth.to_fasta_text(synth.headers_for(g["N"], g.get("pops", 0)), C.g12_matrix(g)))
+        names.append((name, case))
+    return d, names
+
+
+@pytest.mark.parametrize("mode", ["streaming", "direct"])
+def test_g12_rows_through_the_command_line_as_text(gpu, g12, tmp_path, monkeypatch, mode):
+    """Every G12 alignment as a file of one directory, `-d DIR --cds [--jc] [-p pop1,pop2]`: sites_S and sites_N are the
+    reference's characters, every other column within its tolerance (integers and text equal).  Both ingest modes: the
+    copy pipeline (small slots, so the ties sit in different batches) and the direct mode of small jobs."""
+    if mode == "streaming":
+        monkeypatch.setenv("PFA_INGEST_NO_DIRECT", "1")
+        monkeypatch.setenv("PFA_INGEST_SLOT_BYTES", str(1 << 20))
+    root = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    root = os.path.join(root, f"pfa_g12_{os.getpid()}_{mode}")
+    os.makedirs(root)
+    try:
+        n_tie_rows = 0
+        for pops in (False, True):
+            d, names = _write_dir(root, g12["cases"], pops)
+            assert names
+            for jc in (False, True):
+                argv = ["-d", d, "-s", "--cds"] + (["--jc"] if jc else []) + (["-p", "pop1,pop2"] if pops else [])
+                rc, out = run_cli(argv)
+                assert rc == 0
+                got = out.rstrip("\n").split("\n")
+                want = []
+                for name, case in names:
+                    if case["gen"]["L"] % 3:
+                        want.append((f"# CDS sequence length is not a multiple of 3: {name}", False))     # PolyFastA.py:114-119
+                    for key in (["pop1", "pop2"] if pops else ["NA"]):
+                        want.append((case["keys"][key]["row_jc" if jc else "row"].replace("x.fa", name, 1), case["keys"][key]["tie"]))
+                assert len(got) == len(want), (argv, len(got), len(want))
+                for a, (b, tie) in zip(got, want):
+                    if b.startswith("#"):
+                        assert a == b
+                        continue
+                    assert a.split(",")[:3] == b.split(",")[:3], (argv, a, b)          # file, sites_S, sites_N: the text
+                    assert C.row_matches(a, b, True, jc) is None, (argv, a, b)
+                    n_tie_rows += int(tie)
+        assert n_tie_rows >= 40
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def test_api_mirror_returns_the_references_count_syn(gpu, g12):
+    """api.getvarCDSsites(d, L)[0] == ref.getvarCDSsites(d, L)[0], bit for bit (repr), on ties and on ordinary alignments
+    (G5's count_syn): the API mirror always replays the reference's accumulation."""
+    n = 0
+    for case in g12["cases"]:
+        g = case["gen"]
+        if g["N"] > 200:
+            continue
+        d = synth.to_dict(synth.headers_for(g["N"], g.get("pops", 0)), C.g12_matrix(g))
+        for key, k in case["keys"].items():
+            grp = d if key == "NA" else {h: s for h, s in d.items() if key in h}
+            got = api.getvarCDSsites(grp, g["L"])[0]
+            if k["count_syn_order_free"]:
+                assert repr(got) == k["count_syn"], (g, key)
+                n += 1
+            assert round(got, 2) == round(float(k["count_syn"]), 2)
+    assert n >= 8
+    for rec in C.load("g5_cds.json"):
+        d = rec["literal"] if "literal" in rec else C.dict_from_gen(rec["gen"])
+        got = api.getvarCDSsites(d, rec["L"])[0]
+        assert abs(got - rec["cds"]["count_syn"]) <= 1e-12 * max(1.0, rec["cds"]["count_syn"])
+
+
+def test_pipe_and_single_file_paths_print_the_tie_like_the_reference(gpu, g12, tmp_path, monkeypatch):
+    """the small-batch paths (one file with -f: the direct ingest; --pipe: scan_batch) on a G12 tie"""
+    import sys
+    case = next(c for c in g12["cases"] if not c["gen"].get("pops") and c["gen"]["N"] == 50 and c["keys"]["NA"]["tie"])
+    g = case["gen"]
+    text = synth.to_fasta_text(synth.headers_for(g["N"]), C.g12_matrix(g))
+    f = tmp_path / "x.fa"
+    f.write_text(text)
+    want = case["keys"]["NA"]["row"]
+    rc, out = run_cli(["-f", str(f), "-s", "--cds"])
+    assert rc == 0 and out.rstrip("\n").split(",")[:3] == want.split(",")[:3]
+    monkeypatch.setattr(sys, "stdin", io.TextIOWrapper(io.BytesIO(text.encode())))
+    rc, out = run_cli(["--pipe", "-s", "--cds", "-n", "x.fa"])
+    assert rc == 0 and out.rstrip("\n").split(",")[:3] == want.split(",")[:3], (out, want)
