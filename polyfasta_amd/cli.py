@@ -262,6 +262,8 @@ def process_pipe(indexed_paths, args):
         from ._lib import PFA_ERR_UNSUPPORTED, PfaError
         try:
             raw = sys.stdin.buffer.read()
+            if not raw.isascii():      # the reference reads TEXT (sys.stdin.readlines(), :231): what a byte >= 0x80 is, or whether
+                raise PfaError(PFA_ERR_UNSUPPORTED, "standard input holds bytes that are not ASCII")       # it kills the run, is the text layer's call
             aln = fasta.parse_fasta_bytes(raw, 128)
             status = PFA_FILE_NOT_FASTA if aln is None else (0 if aln.same_length else PFA_FILE_UNEQUAL)
         except PfaError as e:
@@ -515,7 +517,7 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
             # a file that cannot be read (a subdirectory inside --dir, a vanished or unreadable file): the reference prints every
             # row before it and dies with the OSError at its open() (PolyFastA.py:104-108, :239); the caller does the same
             # (run_files: rows of the files below it, flush, then raise_unreadable).  Such files yield no rows here.
-            io_error = int(b.file_idx[st == PFA_ERR_IO].min())
+            io_error = int(b.file_idx[st == PFA_ERR_IO].min())      # (a file that is not text may join it below)
         bad = bad | (st == PFA_FILE_UNSUPPORTED)      # unequal BYTE lengths and non-ASCII characters: the loader could not tell
         odd = (st != 0) | bad
         if args.cds:
@@ -532,13 +534,16 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
                 specials.append((fidx, 0, "stdout", f"# file {path} is not FASTA!"))                        # :247 (always stdout)
             elif st[k] == PFA_FILE_UNEQUAL:
                 specials.append((fidx, 0, "comment", f"# Sequences do not have the same length: {name}"))   # :135-140
-            elif bad[k]:    # non-ASCII characters in sequence lines: this file is read as text, the way the reference reads it
+            elif bad[k]:    # bytes that are not ASCII: this file is read as text, the way the reference reads it
                 got = None
                 try:
                     with open(path, "r") as fh:                                                              # :239
                         got = text_alignment_units(fasta.read_text_alignment(fh), path, args, keys)
-                except UnicodeDecodeError:      # not text in the locale's encoding (the reference dies with this error here)
-                    pass
+                except UnicodeDecodeError:
+                    # not text in the locale's encoding: the reference dies in its read loop (:239-240) after the rows of the
+                    # files before this one — the caller's way out for a file that cannot be read (run_files: raise_unreadable)
+                    io_error = fidx if io_error is None else min(io_error, fidx)
+                    continue
                 if got is None:
                     specials.append((fidx, 0, "comment", f"# Sequences hold non-ASCII characters (not supported, one byte per base): {name}"))
                 else:
@@ -584,9 +589,12 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
 
 
 def raise_unreadable(path):
-    """the OSError the reference dies with at its open() of this path (PolyFastA.py:239): IsADirectoryError, FileNotFoundError,
-    PermissionError ..."""
-    open(path, "r").close()
+    """the error the reference dies with reading this path (PolyFastA.py:239-240): the OSError of its open() —
+    IsADirectoryError, FileNotFoundError, PermissionError ... — or the UnicodeDecodeError of its read loop over a file that
+    is not text in the locale's encoding"""
+    with open(path, "r") as f:
+        for _ in f:
+            pass
     raise OSError(f"cannot read {path}")
 
 
@@ -806,8 +814,17 @@ def run_files(paths, args, sink, rank, world, comm, keys, directory=None):
             sys.stdout.flush()
             if comm is not None:
                 comm.barrier()
+            # Rank 0 dies first and in full: a launcher (torchrun, dist.spawn_ranks) ends the other ranks as soon as one of them
+            # leaves with an error, so the reference's traceback is on stderr before anybody exits; the others wait for it.
             if rank == 0:
-                raise_unreadable(paths[fail_at])
+                try:
+                    raise_unreadable(paths[fail_at])
+                except BaseException:      # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    sys.stderr.flush()
+            if comm is not None:
+                comm.barrier()
             raise SystemExit(1)
         tb = time.perf_counter()
         if comm is not None:

@@ -89,10 +89,43 @@ inline uint64_t rstrip_end(const uint8_t* t, uint64_t b, uint64_t e) {
 // fasta_index_impl above (PolyFastA.py:227-250).
 namespace pfa {
 
+bool valid_utf8(const uint8_t* p, uint64_t n) {
+  uint64_t i = 0;
+  while (i < n) {
+    const uint8_t c = p[i];
+    if (c < 0x80u) { ++i; continue; }
+    uint32_t need;
+    uint8_t lo = 0x80u, hi = 0xBFu;      // range of the first continuation byte
+    if (c >= 0xC2u && c <= 0xDFu) need = 1;
+    else if (c == 0xE0u) { need = 2; lo = 0xA0u; }
+    else if (c >= 0xE1u && c <= 0xECu) need = 2;
+    else if (c == 0xEDu) { need = 2; hi = 0x9Fu; }
+    else if (c == 0xEEu || c == 0xEFu) need = 2;
+    else if (c == 0xF0u) { need = 3; lo = 0x90u; }
+    else if (c >= 0xF1u && c <= 0xF3u) need = 3;
+    else if (c == 0xF4u) { need = 3; hi = 0x8Fu; }
+    else return false;
+    if (i + need >= n) return false;      // truncated
+    if (p[i + 1] < lo || p[i + 1] > hi) return false;
+    for (uint32_t k = 2; k <= need; ++k)
+      if ((p[i + k] & 0xC0u) != 0x80u) return false;
+    i += need + 1u;
+  }
+  return true;
+}
+
+// a line outside the kept sequence lines: any byte >= 0x80 sends it through the validator (rare)
+static inline bool line_text_ok(const uint8_t* p, uint64_t n) {
+  uint8_t acc = 0;
+  for (uint64_t i = 0; i < n; ++i) acc |= p[i];
+  return acc < 0x80u || valid_utf8(p, n);
+}
+
 int64_t index_compact(uint8_t* text, uint64_t n_text, std::vector<pfa_fasta_row>& rows, IndexScratch& sc) {
   rows.clear();
   sc.by_name.clear();
   sc.spans.clear();
+  sc.bad_text = false;
   if (!text && n_text) { set_error("index_compact: text is NULL"); return PFA_ERR_ARG; }
   // a file without any '\r' (the usual case) needs no second look at its lines
   const bool has_cr = n_text && memchr(text, '\r', n_text) != nullptr;
@@ -112,6 +145,7 @@ int64_t index_compact(uint8_t* text, uint64_t n_text, std::vector<pfa_fasta_row>
     }
     if (text[pos] == '>') {
       if (have_head) sc.spans[cur].end = pos;
+      if (!line_text_ok(text + pos, e - pos)) sc.bad_text = true;
       const uint64_t nb = pos + 1, ne = rstrip_end(text, nb > e ? e : nb, e);
       std::string_view name(reinterpret_cast<const char*>(text + nb), ne > nb ? ne - nb : 0);
       auto it = sc.by_name.find(name);
@@ -138,6 +172,8 @@ int64_t index_compact(uint8_t* text, uint64_t n_text, std::vector<pfa_fasta_row>
         rows[cur].seq_len += (uint32_t)add;
         sc.spans[cur].n_lines += 1;
       }
+    } else if (e > pos && !line_text_ok(text + pos, e - pos)) {
+      sc.bad_text = true;      // a line nobody keeps (before the first header, behind an empty one): the reference decodes it all the same
     }
     pos = nx;
   }

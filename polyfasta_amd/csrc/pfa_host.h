@@ -28,7 +28,15 @@ struct IndexScratch {
   struct Span { uint64_t first_line, end; uint32_t n_lines; };
   std::unordered_map<std::string_view, uint32_t> by_name;
   std::vector<Span> spans;
+  // out: some line that is NOT a kept sequence line (a header, text before the first header or behind an empty one) is not
+  // valid UTF-8.  The reference decodes every line of a file (PolyFastA.py:239-240) and dies with UnicodeDecodeError on such
+  // a file; the caller hands it back to the host language, which reads it the reference's way.  (Sequence lines are looked
+  // at where their bytes are touched anyway: by the card, or by the loader for files it does not upload.)
+  bool bad_text = false;
 };
+
+// strict UTF-8 as Python decodes it (no overlong forms, no surrogates, nothing above U+10FFFF)
+bool valid_utf8(const uint8_t* p, uint64_t n);
 
 // The records of one FASTA text (readfasta's rules, PolyFastA.py:227-250) in one pass; records
 // written on several lines are compacted in place so that every record's sequence is one run

@@ -489,7 +489,8 @@ void worker_body(pfa_ingest* g) {
       if (f.status == 0) {
         const int64_t n = index_compact(text.data(), size, rows, sc);
         if (n == PFA_ERR_FORMAT && strncmp(pfa_last_error(), "not FASTA", 9) == 0) {
-          f.status = PFA_FILE_NOT_FASTA;
+          // (the reference decodes the whole file before it says so: bytes that are not text make it die first, :239-240)
+          f.status = valid_utf8(text.data(), size) ? PFA_FILE_NOT_FASTA : PFA_FILE_UNSUPPORTED;
         } else if (n < 0) {
           std::lock_guard<std::mutex> lk(g->mu);
           fail(g, (int)n, path + ": " + pfa_last_error());
@@ -508,6 +509,9 @@ void worker_body(pfa_ingest* g) {
               if (high) { f.status = PFA_FILE_UNSUPPORTED; break; }
             }
           }
+          // a header (or a line nobody keeps) that is not valid UTF-8: the reference dies decoding it (PolyFastA.py:239-240);
+          // the caller reads the file the reference's way and does the same
+          if (sc.bad_text) f.status = PFA_FILE_UNSUPPORTED;
           if (f.status == 0) {
             // the rows in transport form, each on a 16-byte boundary: two bits per base when the row is
             // clean A/C/G/T, its bytes otherwise

@@ -17,7 +17,8 @@ Families: G1 examples, G2 synthetic grid, G3 odd symbols and
 FASTA syntax, G4 exhaustive codon-set tables, G5 coding alignments, G6
 populations, G7 command-line transcripts, G8 the BASELINE.json configurations at their full sizes, G9 sequences
 with non-ASCII characters, G10 units of hundreds to 2^20 rows, G11 a directory entry that cannot be read, G12 coding
-alignments whose synonymous-site count is a two-decimal rounding tie.
+alignments whose synonymous-site count is a two-decimal rounding tie, G13 odd inputs through the command line (the G3 texts
+as a directory, population-key edges, the same path twice, a file that is not valid UTF-8).
 """
 import os
 import sys
@@ -794,7 +795,124 @@ def g12():
     dump("g12_rounding_ties.json", {"dropped_hash_seed_dependent": dropped, "cases": out})
 
 
+# ------------------------------------------------------- G13 odd inputs through the command line
+def ref_cli(args, stdin_bytes=None):
+    p = subprocess.run([sys.executable, os.path.join(REF_DIR, "PolyFastA.py")] + args, input=stdin_bytes, capture_output=True,
+                       env={**os.environ, "PYTHONHASHSEED": "0", "PYTHONUTF8": "1"})
+    return p
+
+
+def g13():
+    """What the reference's COMMAND LINE prints for the awkward inputs the other families pin at function level:
+      (a) the twenty G3 texts as the files of one directory, `-d` and `-d --cds --jc` (zero-length sequences, control white
+          space, `>` inside a sequence line, empty headers ...): stdout and exit code;
+      (b) the same path twice after `-f` (PolyFastA.py:104: sorted(), no de-duplication);
+      (c) population keys at their edges, as G6 does it (print_result per key on the split the reference intends, :123-134):
+          an empty key (`-p pop1,` / `-p ,`: '' is in every header), a repeated key, a key equal to a whole header, and an
+          alignment of zero-length sequences with keys, coding and not;
+      (d) a file that is not valid UTF-8 between two good ones: the rows before it, then UnicodeDecodeError, exit code 1
+          (:239-240) — `-d`, `-d --cds --jc -o out.csv -s`, the byte in a header line instead, and `--pipe`."""
+    out = {}
+    tmp = tempfile.mkdtemp()
+
+    def rel(t):
+        return t.replace(tmp + "/", "{TMP}/")
+
+    # (a)
+    d3 = os.path.join(tmp, "g3")
+    os.makedirs(d3)
+    for name, text in G3_TEXTS.items():
+        with open(os.path.join(d3, name + ".fa"), "w", newline="") as fh:
+            fh.write(text)
+    out["g3_dir"] = {}
+    for label, extra in (("plain", []), ("cds_jc", ["--cds", "--jc"]), ("cds", ["--cds"])):
+        p = ref_cli(["-d", d3] + extra)
+        out["g3_dir"][label] = {"args": ["-d", "{TMP}/g3"] + extra, "stdout": rel(p.stdout.decode()), "returncode": p.returncode,
+                                "stderr_tail": (p.stderr.decode().strip().splitlines() or [""])[-1]}
+    # the reference dies under --cds at the first file whose non-synonymous site count is zero while a site varies
+    # (polymorphism() divides by it, :509-517): the same directory without the files it dies on, so that the ones behind them count too
+    removed = []
+    while True:
+        p = ref_cli(["-d", d3, "--cds", "--jc"])
+        if p.returncode == 0:
+            break
+        last = p.stdout.decode().rstrip("\n").split("\n")[-1]
+        name = last.split(": ")[-1] if last.startswith("#") else None
+        nxt = sorted(os.listdir(d3))
+        victim = name if name in nxt else nxt[nxt.index(last.split(",")[0]) + 1]
+        removed.append({"file": victim, "error": p.stderr.decode().strip().splitlines()[-1]})
+        os.unlink(os.path.join(d3, victim))
+    out["g3_dir"]["cds_jc_survivors"] = {"args": ["-d", "{TMP}/g3", "--cds", "--jc"], "removed": removed, "stdout": rel(p.stdout.decode()), "returncode": 0}
+    # (b)
+    ex = os.path.join(HERE, "example_theta_0.01")
+    p = ref_cli(["-f", f"{ex}/file2.fa", f"{ex}/file1.fa", f"{ex}/file2.fa"])
+    out["same_path_twice"] = {"args": ["-f", "{GOLDEN}/example_theta_0.01/file2.fa", "{GOLDEN}/example_theta_0.01/file1.fa",
+                                       "{GOLDEN}/example_theta_0.01/file2.fa"], "stdout": p.stdout.decode(), "returncode": p.returncode}
+    # (c)
+    g = dict(seed=601, aln=0, N=60, L=3000, theta=0.02, pops=2)
+    d = gen_case(**g)
+    first = next(iter(d))
+    edge = []
+    for label, typed in (("trailing_comma", "pop1,"), ("only_commas", ","), ("repeated", "pop1,pop1"), ("whole_header", first + ",pop2"),
+                         ("empty_between", "pop2,,pop1")):
+        rows = []
+        for key in typed.split(","):
+            grp = {h: s for h, s in d.items() if key in h}
+            assert grp == orc.split_pop(d, key) and grp
+            per = {}
+            for cds in (False, True):
+                for jc in (False, True):
+                    row = capture(ref.print_result, grp, 3000, cds, "", "a", "x.fa", key, True, 0, jc).rstrip("\n")
+                    assert_rows_close(orc.result_row(grp, 3000, cds, "x.fa", key, jc), row)
+                    per[f"cds={int(cds)}|jc={int(jc)}"] = row
+            rows.append({"key": key, "N": len(grp), **per})
+        edge.append({"label": label, "typed": typed, "rows": rows})
+    out["pops_edges"] = {"gen": g, "cases": edge}
+    zero = {"pop1_a": "", "pop2_b": "", "pop1_c": ""}
+    zrows = []
+    for key in ("pop1", "", "pop2", "absent"):
+        grp = {h: s for h, s in zero.items() if key in h}
+        if not grp:
+            zrows.append({"key": key, "N": 0})
+            continue
+        per = {}
+        for cds in (False, True):
+            per[f"cds={int(cds)}|jc=0"] = capture(ref.print_result, grp, 0, cds, "", "a", "zero.fa", key, True, 0, False).rstrip("\n")
+        zrows.append({"key": key, "N": len(grp), **per})
+    out["pops_zero_length"] = {"text": "".join(f">{h}\n" for h in zero), "typed": "pop1,,pop2,absent", "rows": zrows}
+    # (d)
+    good1 = open(f"{ex}/file1.fa", "rb").read()
+    good3 = open(f"{ex}/file3.fa", "rb").read()
+    lines = open(f"{ex}/file2.fa", "rb").read().split(b"\n")
+    seq_bad = list(lines)
+    seq_bad[5] = seq_bad[5][:40] + b"\x80" + seq_bad[5][41:]            # a lone continuation byte inside the third record's sequence line
+    head_bad = list(lines)
+    head_bad[2] = head_bad[2] + b"\xff"                                   # ... or in a header line
+    und = {}
+    for label, blob in (("in_sequence", b"\n".join(seq_bad)), ("in_header", b"\n".join(head_bad))):
+        dd = os.path.join(tmp, "und_" + label)
+        os.makedirs(dd)
+        for fn, data in (("a_good.fa", good1), ("b_bad.fa", blob), ("c_good.fa", good3)):
+            with open(os.path.join(dd, fn), "wb") as fh:
+                fh.write(data)
+        runs = {}
+        p = ref_cli(["-d", dd])
+        runs["dir"] = {"args": ["-d", "{TMP}/und_" + label], "stdout": rel(p.stdout.decode()), "returncode": p.returncode,
+                       "stderr_tail": p.stderr.decode().strip().splitlines()[-1]}
+        csv = os.path.join(tmp, f"und_{label}.csv")
+        p = ref_cli(["-d", dd, "--cds", "--jc", "-o", csv, "-s"])
+        runs["dir_cds_jc_out_silent"] = {"args": ["-d", "{TMP}/und_" + label, "--cds", "--jc", "-o", "{TMP}/und_" + label + ".csv", "-s"],
+                                         "stdout": rel(p.stdout.decode()), "file": open(csv).read(), "returncode": p.returncode,
+                                         "stderr_tail": p.stderr.decode().strip().splitlines()[-1]}
+        p = ref_cli(["--pipe"], stdin_bytes=blob)
+        runs["pipe"] = {"args": ["--pipe"], "stdout": p.stdout.decode(), "returncode": p.returncode, "stderr_tail": (p.stderr.decode().strip().splitlines() or [""])[-1]}
+        und[label] = {"bad_file_hex": blob.hex(), "runs": runs}
+    out["undecodable"] = {"layout": ["a_good.fa = example file1.fa", "b_bad.fa", "c_good.fa = example file3.fa"], **und}
+    shutil.rmtree(tmp)
+    dump("g13_cli_odd_inputs.json", out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()
