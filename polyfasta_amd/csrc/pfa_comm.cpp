@@ -209,16 +209,28 @@ int pfa_comm_gatherv(const void* send_host, uint64_t send_bytes, void* recv_host
   uint8_t* const d_recv = g_comm.d_stage + send_span;
   if (send_bytes) PFA_HIP(hipMemcpyAsync(d_send, send_host, (size_t)send_bytes, hipMemcpyHostToDevice, st));
   PFA_NCCL(g_comm.api.GroupStart());
+  // inside the group an error does not return: the group is closed first (a library must not leave RCCL with an open group)
+  ncclResult_t first_err = ncclSuccess;
+  const char* what = "";
   if (me == root) {
     uint64_t off = 0;
-    for (int r = 0; r < w; ++r) {
-      if (counts[r] && r != me) PFA_NCCL(g_comm.api.Recv(d_recv + off, (size_t)counts[r], ncclUint8, r, g_comm.comm, st));
+    for (int r = 0; r < w && first_err == ncclSuccess; ++r) {
+      if (counts[r] && r != me) {
+        first_err = g_comm.api.Recv(d_recv + off, (size_t)counts[r], ncclUint8, r, g_comm.comm, st);
+        what = "ncclRecv";
+      }
       off += counts[r];
     }
   } else if (send_bytes) {
-    PFA_NCCL(g_comm.api.Send(d_send, (size_t)send_bytes, ncclUint8, root, g_comm.comm, st));
+    first_err = g_comm.api.Send(d_send, (size_t)send_bytes, ncclUint8, root, g_comm.comm, st);
+    what = "ncclSend";
   }
-  PFA_NCCL(g_comm.api.GroupEnd());
+  const ncclResult_t end_err = g_comm.api.GroupEnd();
+  if (first_err != ncclSuccess || end_err != ncclSuccess) {
+    const bool inner = first_err != ncclSuccess;
+    pfa::set_error("pfa_comm_gatherv: %s failed: %s", inner ? what : "ncclGroupEnd", g_comm.api.GetErrorString(inner ? first_err : end_err));
+    return PFA_ERR_HIP;
+  }
   if (me == root) {
     uint64_t off = 0;
     for (int r = 0; r < me; ++r) off += counts[r];
