@@ -82,15 +82,38 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ inline uint32_t mbcnt64(uint64_t m) {
   return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
 }
+// Sum over the 64 lanes, the same in every lane afterwards: DPP moves only (six VALU adds and a readlane).  __shfl_xor goes through
+// ds_bpermute, i.e. six dependent round trips through the LDS queue per sum — about a microsecond for the three sums at the end of
+// a chunk and three for a coding chunk's ten, 4-12 % of the life of a workgroup that scans four tiles (round 5).
 __device__ inline uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);   // row_half_mirror: the other quad of eight lanes
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);   // row_mirror: the other half of the row of sixteen
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// 64-bit: four 32-bit sums of 16-bit limbs (none can overflow), step by step next to each other so that one chain's add fills
+// the others' DPP wait states
 __device__ inline unsigned long long wave_sum(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  uint32_t a = (uint32_t)v & 0xFFFFu, b = (uint32_t)v >> 16, c = (uint32_t)(v >> 32) & 0xFFFFu, d = (uint32_t)(v >> 48);
+#define PFA_SUM_STEP(ctrl, rows)                                                         \
+  a += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, ctrl, rows, 0xF, false); \
+  b += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b, ctrl, rows, 0xF, false); \
+  c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, ctrl, rows, 0xF, false); \
+  d += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, ctrl, rows, 0xF, false);
+  PFA_SUM_STEP(0xB1, 0xF)
+  PFA_SUM_STEP(0x4E, 0xF)
+  PFA_SUM_STEP(0x141, 0xF)
+  PFA_SUM_STEP(0x140, 0xF)
+  PFA_SUM_STEP(0x142, 0xA)
+  PFA_SUM_STEP(0x143, 0xC)
+#undef PFA_SUM_STEP
+  return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)a, 63) +
+         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)b, 63) << 16) +
+         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)c, 63) << 32) +
+         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)d, 63) << 48);
 }
 // sum over the 4 lanes of a quad with DPP quad_perm moves (VALU only; __shfl_xor would go
 // through ds_bpermute and the LDS queue)
@@ -168,8 +191,11 @@ __device__ inline uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; 
 // held in scalar registers: lane c stands for codon c (`my_info` = annot_info[c], `my_same` =
 // same_annot[c]), so the multiplicity rule for three or more codons needs no loop — a codon's
 // label multiplicity is one popcount, and "some label occurs at least t times" is one ballot.
-__device__ inline uint32_t classify_uniform(unsigned long long ms, uint32_t lane, uint32_t my_info,
-                                            unsigned long long my_same) {
+// Out of line (round 5): a codon column with two or three variable positions comes up about once in two tiles, and the pair
+// table's address arithmetic and the multiplicity rule's scalar state no longer weigh on the registers of the tile loop.
+__device__ __attribute__((noinline)) uint32_t classify_uniform(unsigned long long ms_, uint32_t lane, uint32_t my_info,
+                                                               unsigned long long my_same) {
+  const unsigned long long ms = wave_uniform(ms_);   // (arguments arrive in vector registers)
   const int k = __popcll(ms);
   if (k < 2) return 0u;
   if (k == 2) {

@@ -20,6 +20,58 @@
 
 namespace pfa {
 
+// Tier 2, the rare columns (three or more alleles, ~1 % of the variable sites; any byte outside A C G T - N): the column of a
+// tile in LDS (`col_off`: byte offset of its first row, rows `tw` bytes apart) walked again with six counters by the 2^lps_log
+// lanes of the site's group (`ph` = this lane's place in it), and any other byte value by the exact generic path
+// (sum over such rows i of #{j : x_j == x_i}).  Out of line (round 5): its twelve counters and three loops no longer sit in
+// the register allocation of the walk every variable site takes.  Lanes with `mine` false come along (the DPP sums want their
+// groups whole) and get zeros.
+struct OtherAlleles {
+  uint32_t sumsq, second, pres;
+};
+__device__ __attribute__((noinline)) OtherAlleles walk_other_alleles(uint32_t col_off, uint32_t tw, uint32_t N, uint32_t ph,
+                                                                     uint32_t lps_log, bool mine) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint8_t* const colp = lds + col_off;
+  const uint32_t LPS = 1u << lps_log;
+  uint32_t cA = 0, cC = 0, cG = 0, cT = 0, cGap = 0, cNn = 0;
+  if (mine) {
+#pragma unroll 2
+    for (uint32_t r = ph; r < N; r += LPS) {
+      const uint32_t v = colp[r * tw];
+      cA += (v == 'A');
+      cC += (v == 'C');
+      cG += (v == 'G');
+      cT += (v == 'T');
+      cGap += (v == '-');
+      cNn += (v == 'N');
+    }
+  }
+  cA = group_sum(cA, lps_log);
+  cC = group_sum(cC, lps_log);
+  cG = group_sum(cG, lps_log);
+  cT = group_sum(cT, lps_log);
+  cGap = group_sum(cGap, lps_log);
+  cNn = group_sum(cNn, lps_log);
+  uint32_t sumsq = cA * cA + cC * cC + cG * cG + cT * cT + cGap * cGap + cNn * cNn;
+  const uint32_t n_other = mine ? N - (cA + cC + cG + cT + cGap + cNn) : 0u;
+  uint32_t extra = 0u;
+  if (n_other != 0u) {
+    for (uint32_t i = ph; i < N; i += LPS) {
+      const uint32_t xi = colp[i * tw];
+      const bool six = xi == 'A' || xi == 'C' || xi == 'G' || xi == 'T' || xi == '-' || xi == 'N';
+      if (!six) {
+        uint32_t cnt = 0u;
+        for (uint32_t j = 0; j < N; ++j) cnt += (colp[j * tw] == xi);
+        extra += cnt;
+      }
+    }
+  }
+  if (__any(n_other != 0u)) sumsq += group_sum(extra, lps_log);
+  const uint32_t hi1 = umax(cA, cC), lo1 = umin(cA, cC), hi2 = umax(cG, cT), lo2 = umin(cG, cT);
+  return {sumsq, umax(umin(hi1, hi2), umax(lo1, lo2)), (cA ? 1u : 0u) | (cC ? 2u : 0u) | (cT ? 4u : 0u) | (cG ? 8u : 0u)};
+}
+
 // STAGE: cache policy of the tile loads, 2 = non-temporal (default), 0 = default policy (A/B).
 // MAPPED: the bucket's units read their rows through a row-index list (--pops).  BITMAPS: the plan
 // wants per-site bitmaps.  Both compile their branches — and the scalar registers they pin — out
@@ -217,44 +269,12 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
         uint32_t second = (xc && yc) ? umin(c1, c2) : 0u;   // second-largest A/C/G/T count (PolyFastA.py:279-281)
         uint32_t pres = (xc ? 1u << base_code(x) : 0u) | (yc ? 1u << base_code(y) : 0u);   // which of A, C, T, G occur
         const bool multi = act && c1 + c2 != N;   // the same in all lanes of the site's group
-        if (__any(multi)) {
+        if (__any(multi)) {      // (~1 % of the variable sites: out of line, walk_other_alleles)
+          const OtherAlleles o = walk_other_alleles(lo.tile + s, TW, N, ph, lps_log, multi);
           if (multi) {
-            uint32_t cA = 0, cC = 0, cG = 0, cT = 0, cGap = 0, cNn = 0;
-#pragma unroll 2
-            for (uint32_t r = ph; r < N; r += LPS) {
-              const uint32_t v = colp[r * TW];
-              cA += (v == 'A');
-              cC += (v == 'C');
-              cG += (v == 'G');
-              cT += (v == 'T');
-              cGap += (v == '-');
-              cNn += (v == 'N');
-            }
-            cA = group_sum(cA, lps_log);
-            cC = group_sum(cC, lps_log);
-            cG = group_sum(cG, lps_log);
-            cT = group_sum(cT, lps_log);
-            cGap = group_sum(cGap, lps_log);
-            cNn = group_sum(cNn, lps_log);
-            sumsq = cA * cA + cC * cC + cG * cG + cT * cT + cGap * cGap + cNn * cNn;
-            const uint32_t n_other = N - (cA + cC + cG + cT + cGap + cNn);
-            if (n_other != 0u) {
-              // exact path for any other byte value: sum over such rows i of #{j : x_j == x_i}
-              uint32_t extra = 0u;
-              for (uint32_t i = ph; i < N; i += LPS) {
-                const uint32_t xi = colp[i * TW];
-                const bool six = xi == 'A' || xi == 'C' || xi == 'G' || xi == 'T' || xi == '-' || xi == 'N';
-                if (!six) {
-                  uint32_t cnt = 0u;
-                  for (uint32_t j = 0; j < N; ++j) cnt += (colp[j * TW] == xi);
-                  extra += cnt;
-                }
-              }
-              sumsq += group_sum(extra, lps_log);
-            }
-            const uint32_t hi1 = umax(cA, cC), lo1 = umin(cA, cC), hi2 = umax(cG, cT), lo2 = umin(cG, cT);
-            second = umax(umin(hi1, hi2), umax(lo1, lo2));
-            pres = (cA ? 1u : 0u) | (cC ? 2u : 0u) | (cT ? 4u : 0u) | (cG ? 8u : 0u);
+            sumsq = o.sumsq;
+            second = o.second;
+            pres = o.pres;
           }
         }
         if (act && ph == 0u) {
@@ -271,7 +291,9 @@ __global__ void __launch_bounds__(64) scan_kernel(const ScanArgs A) {
     };
     // 128-site tiles (units of 65 to about 200 rows) with few variable sites: 8 lanes per site halve the rows a lane walks and
     // with them the dependent LDS round trips of the walk (N = 200 coding 0.722 -> 0.740, N = 200 0.776 -> 0.786; the 256-site
-    // tiles of units up to 64 rows have 16 rows per lane at most and more than 8 variable sites as a rule: nothing to gain)
+    // tiles of units up to 64 rows have 16 rows per lane at most and more than 8 variable sites as a rule: nothing to gain).
+    // (One body with the lanes per site as a wave-uniform run-time value was tried in round 5: N = 200 0.78 -> 0.68, coding
+    // 0.75 -> 0.62 — the walk wants its stride as a constant.)
     bool wide_walk = false;
     if constexpr (TWP == 128u) wide_walk = P <= 8u;
     if (wide_walk) {

@@ -290,10 +290,11 @@ def test_sequences_with_non_ascii_characters(gpu, tmp_path, monkeypatch):
     got = [ln for ln in out.split("\n") if ln][0]
     assert got.split(",")[1:5] == want.split(",")[1:5]
     C.rows_close("x," + got.split(",", 1)[1], "x," + want.split(",", 1)[1], rel=1e-9, rel_jc=1e-6, jc=False)
-    # not text at all (a lone continuation byte): the reference dies with a UnicodeDecodeError; here the file gets a comment line
+    # not text at all (a lone continuation byte): the reference dies in its read loop with a UnicodeDecodeError (PolyFastA.py:239-240),
+    # and so does this command line (G13, tests/test_cli_odd_gpu.py, pins stdout, exit code and message through a real process)
     (d / "broken.fa").write_bytes(b">a\nAC\x80T\n>b\nACGT\n")
-    rc, out = run_cli(["-f", str(d / "broken.fa"), "-s"])
-    assert out.strip() == "# Sequences hold non-ASCII characters (not supported, one byte per base): broken.fa"
+    with pytest.raises(UnicodeDecodeError):
+        run_cli(["-f", str(d / "broken.fa"), "-s"])
     # the API mirror on the same file: the reference's function names on a dict of text (PolyFastA.py:227-261, :502-520)
     from oracle import polyfasta_oracle as orc
     from polyfasta_amd import api
