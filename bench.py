@@ -152,8 +152,16 @@ class Workload:
     def measure(self, steps, warmup, variant=0):
         """kernel-only figures from HIP events around the launches of `steps` runs"""
         from polyfasta_amd import _lib
-        for _ in range(warmup):
+        # warm by TIME as well as by count: after some tens of milliseconds without work the card drops to a low-power state, and the
+        # launches that follow run 5-12 % slower until its clocks are back (profiles/r05_launch_spread_*: coding N = 5 000 back to back
+        # 7.48-7.64 ms, with 30 ms of idle between launches 7.85-8.61) — what round 4 saw as "0.71-0.77 between runs"
+        t_warm = time.perf_counter()
+        n_warm = 0
+        while n_warm < warmup or (time.perf_counter() - t_warm < 0.08 and n_warm < 400):
             self.plan.run(self.dev, variant=variant)
+            n_warm += 1
+            if n_warm >= warmup:
+                _lib.check(_lib.load().pfa_sync())
         for _ in range(steps):
             self.plan.run(self.dev, variant=variant)
         _lib.check(_lib.load().pfa_sync())
@@ -766,6 +774,9 @@ def main():
                       "sum_H": int(res["H"].sum()),
                       "gathered_records": None if gathered is None else int(gathered.size),
                       "gathered_rank0_equals_fetch": None if gathered is None else bool((gathered[0] == res).all())},
+            # the sources the loaded library was compiled from (pfa_build_id) and the tree's: equal, or _lib.load() would have refused
+            "library": {"build_id": lib.pfa_build_id().decode(), "tree_source_hash": __import__("polyfasta_amd._build", fromlist=["x"]).source_hash(),
+                        "abi": int(lib.pfa_abi_version())},
         }
         DETAIL["headline"] = {"kernel": plan.description, "traffic_source": traffic_source, "kernel_variant": {0: "lds_dma_nt", 2: "lds_dma_default_policy"}[args.variant],
                               "tiles_per_chunk": plan.tiles_per_chunk, "rows_per_chunk": plan.rows_per_chunk, "frac_of_measured_copy_6290": achieved / 6290.0}
