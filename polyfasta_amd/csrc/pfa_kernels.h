@@ -140,6 +140,9 @@ __device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" :::
 // wait for the WHOLE tile a wavefront has just requested ahead of time: the coding pass's table work after the request, meant
 // to run under those loads, then ran behind them (round 4, read off the ISA).  Completion is ordered by the kernels' own
 // wave_lds_sync() (LDS operations of a wavefront complete in order).  PFA_LDS_ATOMIC_WAITS=1 (compile time): the builtin again.
+// REQUIREMENT on every call site: a wave_lds_sync() stands between the last lds_add_u32() on a bin and any read of it (hist and
+// synhist are read at the end of a chunk only, behind one).  Nothing the compiler checks: tests/test_gpu_parity.py builds the
+// library both ways and compares the coding cases of G5 / G10 bit for bit.
 __device__ inline void lds_add_u32(uint32_t* p, uint32_t v) {
 #if defined(PFA_LDS_ATOMIC_WAITS) && PFA_LDS_ATOMIC_WAITS
   atomicAdd(p, v);

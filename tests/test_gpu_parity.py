@@ -258,3 +258,43 @@ def test_device_classifier_all_codon_sets(gpu):
     got = api.classify_codon_sets_on_device(sets)
     bad = np.flatnonzero(got != np.array(want, dtype=np.uint32))
     assert len(bad) == 0, (len(bad), sets[bad[0]], int(got[bad[0]]), want[bad[0]])
+
+
+def test_lds_histogram_adds_without_compiler_waits_equal_the_builtin(gpu, tmp_path):
+    """lds_add_u32 (pfa_kernels.h) issues `ds_add_u32` from inline asm so that the compiler's waitcnt insertion does not see it;
+    its correctness rests on in-order LDS completion within a wavefront and on a wave_lds_sync() in front of every read of the
+    bins — nothing the compiler checks.  Build the library both ways (-DPFA_LDS_ATOMIC_WAITS=1: the atomicAdd builtin) and
+    compare every integer of the coding cases of G5 and of G10 up to 5 000 rows, bit for bit."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from polyfasta_amd import _lib, scan
+from tests import _cases as C
+_lib.init(0)
+out = {}
+cases = [("g5_%%d" %% i, C.matrix_from_gen(r["gen"]) if "gen" in r else C.matrix_from_literal(r["literal"])) for i, r in enumerate(C.load("g5_cds.json"))]
+cases += [("g10_%%d" %% i, C.g10_matrix(c["gen"])) for i, c in enumerate(C.load("g10_many_rows.json")) if c["coding"] and c["N"] <= 5000]
+b = scan.Batch(stride_align=128)
+for name, m in cases:
+    b.add_unit(b.add_matrix(m), cds=True)
+o = scan.scan_batch(b)
+np.savez(sys.argv[1], results=o.results, sfs=o.sfs_flat, syn=o.syn_num)
+"""
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    from polyfasta_amd import _build
+    alt = str(tmp_path / "libpfa_builtin_atomics.so")
+    _build.build(extra_flags=["-DPFA_LDS_ATOMIC_WAITS=1"], lib_path=alt)
+    outs = []
+    for i, lib in enumerate((None, alt)):
+        env = dict(__import__("os").environ)
+        if lib:
+            env["PFA_LIB"] = lib
+        f = str(tmp_path / f"out{i}.npz")
+        p = subprocess.run([sys.executable, "-c", code % {"root": root}, f], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(np.load(f))
+    for k in ("results", "sfs", "syn"):
+        assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+    assert int(outs[0]["results"]["seg_S"].sum()) > 100 and int(outs[0]["syn"].sum()) > 1000
