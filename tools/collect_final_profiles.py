@@ -33,9 +33,9 @@ for tag, label in (("head", "headline"), ("coding", "c4"), ("pops", "pops"), ("n
     for d in sorted(glob.glob(os.path.join(G, f"pmc_{r}_{tag}", "sq*"))):
         f = max(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)   # this run's, not an earlier call's
         per = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            if "scan_" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]:
-                per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for row in csv.DictReader(open(f)):
+            if "scan_" in row["Kernel_Name"] and "kernel" in row["Kernel_Name"]:
+                per[row["Counter_Name"]].append(float(row["Counter_Value"]))
         w = sum(per["SQ_WAVE_CYCLES"]) / max(len(per["SQ_WAVE_CYCLES"]), 1)
         for k, v in per.items():
             agg[k] = (sum(v) / len(v), w)
