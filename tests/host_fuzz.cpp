@@ -62,6 +62,50 @@ static std::string random_fasta() {
   return s;
 }
 
+// pfa::valid_utf8 (pfa_fasta.cpp: which files the loader hands back because the reference would die decoding them, PolyFastA.py:239-240)
+// against a validator written the other way round — decode the code point, then judge it: shortest form, no surrogates, at most
+// U+10FFFF (what CPython's strict UTF-8 decoder accepts).
+namespace pfa { bool valid_utf8(const uint8_t* p, uint64_t n); }
+static bool utf8_by_decoding(const uint8_t* p, size_t n) {
+  size_t i = 0;
+  while (i < n) {
+    const uint32_t c = p[i];
+    uint32_t len, cp;
+    if (c < 0x80) { ++i; continue; }
+    else if ((c & 0xE0) == 0xC0) { len = 2; cp = c & 0x1F; }
+    else if ((c & 0xF0) == 0xE0) { len = 3; cp = c & 0x0F; }
+    else if ((c & 0xF8) == 0xF0) { len = 4; cp = c & 0x07; }
+    else return false;
+    if (i + len > n) return false;
+    for (uint32_t k = 1; k < len; ++k) {
+      if ((p[i + k] & 0xC0) != 0x80) return false;
+      cp = (cp << 6) | (p[i + k] & 0x3F);
+    }
+    static const uint32_t least[5] = {0, 0, 0x80, 0x800, 0x10000};
+    if (cp < least[len] || cp > 0x10FFFF || (cp >= 0xD800 && cp <= 0xDFFF)) return false;
+    i += len;
+  }
+  return true;
+}
+static void fuzz_utf8() {
+  uint8_t buf[24];
+  const uint32_t n = below(sizeof buf + 1);
+  // bytes drawn so that multi-byte sequences, their edges (E0 A0, ED 9F / A0, F0 90, F4 8F / 90) and truncations come up often
+  static const uint8_t pool[] = {0x41, 0x7F, 0x80, 0x8F, 0x90, 0x9F, 0xA0, 0xBF, 0xC0, 0xC1, 0xC2, 0xDF, 0xE0, 0xE1, 0xEC, 0xED, 0xEE, 0xEF,
+                                 0xF0, 0xF1, 0xF3, 0xF4, 0xF5, 0xFF};
+  for (uint32_t i = 0; i < n; ++i) buf[i] = below(3) ? pool[below(sizeof pool)] : (uint8_t)below(256);
+  uint8_t* exact = (uint8_t*)malloc(n ? n : 1);     // exact-size copy: ASan sees a read past the end of a truncated sequence
+  memcpy(exact, buf, n);
+  const bool a = pfa::valid_utf8(exact, n), b = utf8_by_decoding(exact, n);
+  if (a != b) {
+    fprintf(stderr, "valid_utf8 = %d but decoding says %d for", (int)a, (int)b);
+    for (uint32_t i = 0; i < n; ++i) fprintf(stderr, " %02X", buf[i]);
+    fprintf(stderr, "\n");
+    abort();
+  }
+  free(exact);
+}
+
 static void fuzz_text(const std::string& s) {
   // exact-size heap copy: ASan sees any read past the end
   uint8_t* text = (uint8_t*)malloc(s.size() ? s.size() : 1);
@@ -221,6 +265,7 @@ int main(int argc, char** argv) {
   const char* dir = argc > 2 ? argv[2] : "/tmp";
   for (long i = 0; i < iters; ++i) {
     fuzz_text(random_fasta());
+    for (int k = 0; k < 8; ++k) fuzz_utf8();
     if (i % 16 == 0) fuzz_files(dir);
     fuzz_rows();
   }
