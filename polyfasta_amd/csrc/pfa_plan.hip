@@ -193,8 +193,14 @@ struct Bucket {
 // round 3, 128-site tiles, classic / row-chunked (tools/rows_sweep.sh): 6 waves — N = 192 0.771 / 0.765, 200 0.766 / 0.762,
 // coding 0.736 / 0.664 and 0.720 / 0.709; 5 waves — N = 208 0.691 / 0.726, 224 0.719 / 0.726, 250 0.612 / 0.715, coding 208
 // 0.618 / 0.664, 224 0.652 / 0.659)
+// Single-wavefront workgroups a CU holds by their LDS: the 160 KB are handed out in 512-byte granules (round 5, wave trace: the
+// headline's 13 424 B fit 11 times, not the 12 that 160 KB / 13 424 and hipOccupancyMaxActiveBlocksPerMultiprocessor say).
+static uint32_t waves_by_lds(uint32_t lds_bytes) {
+  return kLdsPerCu / std::max((lds_bytes + 511u) & ~511u, 512u);
+}
+
 static bool classic_fills_cu(uint32_t lds_bytes, uint32_t n, uint32_t tw) {
-  const uint32_t waves = kLdsPerCu / std::max(lds_bytes, 1u);
+  const uint32_t waves = waves_by_lds(lds_bytes);
   return waves >= 6u && (uint64_t)waves * n * tw >= 125000ull;
 }
 
@@ -510,7 +516,7 @@ static BucketKey bucket_of(const pfa_desc& d, bool bitmaps, uint32_t narrow_tw) 
     const uint32_t lds = lds_layout(k.tw, n, k.cds, rowmap).total;
     // units of one bucket share an LDS size: group them by the wavefronts per CU their own size
     // allows, so that nobody loses occupancy to a larger neighbour; 16-bit per-site H up to 64 rows
-    k.waves = std::min(kLdsPerCu / std::max(lds, 1u), 32u) | (k.cds && n <= 64u ? 0x100u : 0u);
+    k.waves = std::min(waves_by_lds(lds), 32u) | (k.cds && n <= 64u ? 0x100u : 0u);
   }
   return k;
 }
