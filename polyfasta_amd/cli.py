@@ -212,8 +212,8 @@ def text_alignment_units(data, path, args, keys):
     from the reference's own reading of it (`fasta.read_text_alignment`): every distinct non-ASCII character gets a byte value of
     its own — the scan only asks whether two rows hold the same symbol and whether a symbol is exactly A, C, G or T — and
     the matrix is scanned on the card as one small batch.  Returns (units, lines): units as (key index or PFA_NO_KEY,
-    n_rows, n_sites, record, syn row, sfs list, sites_S override or None), lines as (sub-order, kind, text); or None when the file holds more than
-    128 distinct non-ASCII characters or no sites."""
+    n_rows, n_sites, record, syn row, sfs list, sites_S override or None), lines as (sub-order, kind, text); or None when the file holds more
+    distinct characters than a byte has values (fasta.byte_codes) or no sites."""
     from ._lib import PFA_NO_KEY
     name = path.split("/")[-1]
     if data is None:

@@ -160,13 +160,20 @@ def read_text_alignment(lines):
 
 
 def byte_codes(seqs):
-    """str.translate table that gives every distinct non-ASCII character of `seqs` a byte value of its own (0x80 ...): the
-    scan only asks whether two rows hold the same symbol and whether a symbol is exactly A, C, G or T.  None when there
-    are more than 128 of them."""
-    others = sorted({c for x in seqs for c in x if ord(c) >= 0x80})
-    if len(others) > 128:
+    """str.translate table that gives every distinct non-ASCII character of `seqs` a byte value of its own: the scan only asks
+    whether two rows hold the same symbol and whether a symbol is exactly A, C, G or T, so any value no other symbol of the
+    alignment uses will do — 0x80 ... 0xFF first, then the ASCII values the alignment leaves free (never A, C, G, T, never 0:
+    the padding of matrix_from_dict).  None when the alignment holds more distinct symbols than a byte has values (one byte
+    per base is the layout of this implementation: well over 200 distinct characters in one alignment)."""
+    chars = {c for x in seqs for c in x}
+    others = sorted(c for c in chars if ord(c) >= 0x80)
+    if len(others) <= 128:
+        return {ord(c): 0x80 + i for i, c in enumerate(others)}
+    used = {ord(c) for c in chars if ord(c) < 0x80} | set(b"ACGT") | {0}
+    free = list(range(0x80, 0x100)) + [v for v in range(1, 0x80) if v not in used]
+    if len(others) > len(free):
         return None
-    return {ord(c): 0x80 + i for i, c in enumerate(others)}
+    return {ord(c): v for c, v in zip(others, free)}
 
 
 def matrix_from_dict(d, seqlen=None) -> np.ndarray:
@@ -179,7 +186,7 @@ def matrix_from_dict(d, seqlen=None) -> np.ndarray:
         seqlen = len(seqs[0]) if seqs else 0
     table = byte_codes(s[:seqlen] for s in seqs)
     if table is None:
-        raise ValueError("more than 128 distinct non-ASCII characters cannot be packed one byte per base")
+        raise ValueError("more distinct characters than a byte has values: they cannot be packed one byte per base")
     out = np.zeros((len(seqs), seqlen), dtype=np.uint8)
     for i, s in enumerate(seqs):
         b = s[:seqlen].translate(table).encode("latin-1")

@@ -563,3 +563,21 @@ def test_loader_threads_are_spread_over_last_level_cache_domains(tmp_path):
     assert dom.tolist() == [(i // 2) % 3 for i in range(len(cpus))]
     assert lib.pfa_host_l3_domains(str(tmp_path / "nope").encode(), None, 0) == 0
     assert lib.pfa_host_l3_domains(None, None, 0) >= 0                    # the machine's own tree: whatever it says
+
+
+def test_byte_codes_use_every_free_byte_value():
+    """fasta.byte_codes: non-ASCII characters get byte values nothing else in the alignment uses — 0x80.. first, then free ASCII
+    values, never A / C / G / T / NUL; only an alignment with more distinct symbols than a byte has values is turned away."""
+    from polyfasta_amd import fasta
+    few = ["ACGé", "ACGñ"]
+    assert fasta.byte_codes(few) == {0xE9: 0x80, 0xF1: 0x81}
+    many = [chr(0x400 + i) for i in range(200)]                     # 200 distinct Cyrillic-block characters
+    seqs = ["ACGT-N" + "".join(many), "ACGTRY" + "".join(reversed(many))]
+    t = fasta.byte_codes(seqs)
+    assert t is not None and len(set(t.values())) == 200
+    assert not set(t.values()) & ({0} | set(b"ACGT-NRY"))          # nothing the alignment itself uses, never A C G T, never the padding
+    m = fasta.matrix_from_dict({"a": seqs[0], "b": seqs[1]})
+    assert m.shape == (2, 206) and (m[0, :4] == np.frombuffer(b"ACGT", dtype=np.uint8)).all()
+    assert len(set(m[0, 6:].tolist())) == 200 and (m[0, 6:] == m[1, 6:][::-1]).all()
+    too_many = ["".join(chr(0x400 + i) for i in range(260))]
+    assert fasta.byte_codes(too_many) is None
