@@ -48,11 +48,12 @@ extern "C" {
 #define PFA_ERR_IO (-8)
 #define PFA_ERR_UNSUPPORTED (-9) /* FASTA packer: a byte >= 0x80 in a sequence line */
 
-/* Rows per scan unit.  Units with many rows are streamed in row chunks, so the
- * bound is what the 32-bit allele counters are sized for; coding units
- * (PFA_FLAG_CDS) share it: above 2 048 rows their per-site H is kept in 56 bits
- * (the reference's getvarCDSsites has no row limit, PolyFastA.py:284-315). */
-#define PFA_MAX_ROWS 1048576u
+/* Rows per scan unit.  The reference has no limit (PolyFastA.py:252-261, :284-315); here every count is 32 bits wide and every
+ * product of counts 64 (units with many rows are streamed in row chunks; coding units above 2 048 rows keep their per-site H in 56
+ * bits), so the bound is where the tests end: 2^24 rows in one unit (a 0.27 GB matrix at 16 sites; checked at that size against the
+ * C oracle and at 2^21 + 3 rows against the reference itself, tests/golden G10).  One row more is refused with
+ * PFA_ERR_TOO_MANY_ROWS, never answered wrongly. */
+#define PFA_MAX_ROWS 16777216u
 #define PFA_MAX_ROWS_CDS PFA_MAX_ROWS
 
 #define PFA_NO_ROW_IDX 0xFFFFFFFFu

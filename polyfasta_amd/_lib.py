@@ -20,7 +20,7 @@ PFA_FLAG_CDS = 1
 PFA_WANT_VAR_BITMAP = 1
 PFA_WANT_SN_BITMAP = 2
 PFA_SYN_BINS = 65
-PFA_MAX_ROWS = 1 << 20
+PFA_MAX_ROWS = 1 << 24
 PFA_MAX_ROWS_CDS = PFA_MAX_ROWS
 PFA_COMM_ID_BYTES = 128
 PFA_ERR_FORMAT = -7

@@ -582,7 +582,10 @@ def g10():
            dict(kind="many", seed=1007, N=70000, L=64, alphabet="ACGT"),
            dict(kind="many", seed=1007, N=70000, L=64, alphabet="ACGT", subset=dict(seed=11, frac=0.95)),
            dict(kind="many", seed=1008, N=1 << 20, L=16, alphabet="ACGT"),
-           dict(kind="many", seed=1009, N=1 << 20, L=16, alphabet="ACGT-N")]
+           dict(kind="many", seed=1009, N=1 << 20, L=16, alphabet="ACGT-N"),
+           # beyond the 2^20 rows that were the ABI's limit until round 5
+           dict(kind="many", seed=1010, N=(1 << 21) + 3, L=16, alphabet="ACGT-N"),
+           dict(kind="many", seed=1010, N=(1 << 21) + 3, L=16, alphabet="ACGT-N", subset=dict(seed=13, frac=0.95))]
     cod = [dict(kind="many", seed=1101, N=128, L=333, alphabet="ACGT"),
            dict(kind="synth", seed=1102, N=160, L=333, theta=0.05, coding=True),
            dict(kind="many", seed=1103, N=200, L=333, alphabet=SYM),
@@ -595,7 +598,8 @@ def g10():
            dict(kind="many", seed=1110, N=70000, L=66, alphabet=SYM),
            dict(kind="many", seed=1111, N=70000, L=66, alphabet="ACGT"),
            dict(kind="many", seed=1111, N=70000, L=66, alphabet="ACGT", subset=dict(seed=12, frac=0.95)),
-           dict(kind="many", seed=1112, N=1 << 20, L=15, alphabet="ACGT")]
+           dict(kind="many", seed=1112, N=1 << 20, L=15, alphabet="ACGT"),
+           dict(kind="many", seed=1113, N=(1 << 21) + 3, L=15, alphabet="ACGT")]
     out = []
     for cds, gens in ((False, non), (True, cod)):
         for g in gens:

@@ -586,14 +586,15 @@ def test_hundred_thousand_tiny_files(gpu, tmp_path):
 
 
 def test_a_million_sequences_in_one_file(gpu, tmp_path):
-    """2^20 sequences of 15 sites in one file (the ABI's row limit; the reference has none, PolyFastA.py:252-261): the record
+    """2^20 sequences of 15 sites in one file (the reference has no row limit, PolyFastA.py:252-261): the record
     index of a million headers, the population split over them (`-p popA,popB`: half a million rows each), 64-bit H,
-    the coding pass; every column against the checker.  One sequence more is refused loudly, never answered wrongly."""
+    the coding pass; every column against the checker.  (More rows than the ABI admits — 2^24 + 1 records — are refused
+    loudly, never answered wrongly: test_more_sequences_than_the_abi_admits.)"""
     import numpy as np
     from oracle import c_oracle
     from oracle import polyfasta_oracle as orc
     from polyfasta_amd import _lib
-    N, L = _lib.PFA_MAX_ROWS, 15
+    N, L = 1 << 20, 15
     rng = np.random.default_rng(5)
     m = np.repeat(np.frombuffer(b"ATGGCTAAAGGTCTA", dtype=np.uint8)[None, :], N, axis=0)
     for col, frac, alt in ((2, 0.3, b"A"), (4, 0.001, b"T"), (5, 0.5, b"G"), (9, 0.02, b"C"), (10, 0.02, b"A"), (14, 1e-5, b"N")):
@@ -615,10 +616,35 @@ def test_a_million_sequences_in_one_file(gpu, tmp_path):
                 o = c_oracle.scan(m, rows=rows, cds=cds)
                 want.append(orc.row_from_counts(name, key or "NA", N if rows is None else len(rows), L, o, cds, jc))
             assert len(got) == len(want) and all(a == b or C.row_matches(a, b, cds, jc) is None for a, b in zip(got, want)), (got, want)
-        with open(path, "ab") as fh:
-            fh.write(b">one_more\n" + m[0].tobytes() + b"\n")
-        with pytest.raises(_lib.PfaError, match="rows"):
-            run_cli(["-f", path, "-s"])
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
+def test_more_sequences_than_the_abi_admits(gpu, tmp_path):
+    """PFA_MAX_ROWS + 1 = 2^24 + 1 records in one file (0.45 GB of text, written as one numpy array): the command line ends with the
+    library's error about the rows; it does not print a row."""
+    import numpy as np
+    from polyfasta_amd import _lib
+    N = _lib.PFA_MAX_ROWS + 1
+    root = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (2 << 30) else str(tmp_path)
+    path = os.path.join(root, f"pfa_too_many_{os.getpid()}.fa")
+    rec = np.empty((N, 26), dtype=np.uint8)                      # ">" + eight digits + "\n" + 15 bases + "\n"
+    rec[:, 0] = ord(">")
+    idx = np.arange(N, dtype=np.int64)
+    for k in range(8):
+        rec[:, 8 - k] = ord("0") + (idx // 10 ** k) % 10
+    rec[:, 9] = rec[:, 25] = ord("\n")
+    rec[:, 10:25] = np.frombuffer(b"ATGGCTAAAGGTCTA", dtype=np.uint8)
+    rec[::7, 12] = ord("A")
+    try:
+        rec.tofile(path)
+        del rec
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            with pytest.raises(_lib.PfaError, match="rows"):
+                cli.main(["-f", path, "-s"])
+        assert buf.getvalue() == ""
     finally:
         if os.path.exists(path):
             os.unlink(path)

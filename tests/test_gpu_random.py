@@ -198,7 +198,7 @@ def _many_row_matrix(rng, n, L, alphabet):
 
 @pytest.mark.parametrize("cds", [False, True])
 def test_units_beyond_65536_rows_match_the_oracle(gpu, cds):
-    """What the ABI advertises (PFA_MAX_ROWS = 2^20; the reference has no limit, PolyFastA.py:252-315) against
+    """What the ABI advertises (PFA_MAX_ROWS = 2^24; the reference has no limit, PolyFastA.py:252-315) against
     the oracle where N^2 and c^2 leave 32 bits: a 70 000-row unit with 3+ alleles per site, gaps, N and IUPAC
     bytes — 64-bit H on the device, SFS bins above the 256 kept in LDS, the 56-bit entries of the coding pass."""
     rng = np.random.default_rng(77 + cds)
@@ -225,14 +225,21 @@ def test_units_beyond_65536_rows_match_the_oracle(gpu, cds):
 
 
 def test_unit_at_the_row_limit(gpu):
-    """PFA_MAX_ROWS rows x 16 sites, coding and not, against the C oracle"""
+    """PFA_MAX_ROWS = 2^24 rows x 16 sites, coding and not, and a 97 % row subset through an index list, against the C oracle"""
     from polyfasta_amd import _lib
     rng = np.random.default_rng(9)
     n = _lib.PFA_MAX_ROWS
+    assert n == 1 << 24
     m = _many_row_matrix(rng, n, 16, "ACGTN")
     o = c_oracle.scan(m)
     r = scan.scan_matrix(m).results[0]
     assert (int(r["seg_sites"]), int(r["H"]), int(r["sfs_bad"])) == (o["S"], o["H"], o["sfs_bad"])
+    assert int(r["H"]) > 2 ** 48
+    rows = np.flatnonzero(rng.random(n) < 0.97).astype(np.uint32)
+    o = c_oracle.scan(m, rows=rows)
+    out = scan.scan_matrix(m, rows=rows)
+    r = out.results[0]
+    assert (int(r["seg_sites"]), int(r["H"]), int(r["sfs_bad"])) == (o["S"], o["H"], o["sfs_bad"]) and out.sfs(0).tolist() == o["sfs"].tolist()
     m = _many_row_matrix(rng, n, 15, "ACGT")
     o = c_oracle.scan(m, cds=True)
     out = scan.scan_matrix(m, cds=True)

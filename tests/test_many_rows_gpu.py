@@ -1,5 +1,5 @@
 """GPU parity in the many-row regime against vectors frozen from the REFERENCE (G10, tests/golden/g10_many_rows.json:
-units of 128 to 2^20 rows; the reference has no row limit, PolyFastA.py:252-261, :284-315).  This is where the
+units of 128 to 2^21 + 3 rows; the reference has no row limit, PolyFastA.py:252-261, :284-315).  This is where the
 row-chunked kernels (`scan_tall_kernel`, its WIDE coding form above 2 048 rows), the 128-site-tile coding kernel at
 101-200 rows, 64-bit H and SFS bins beyond the 256 kept in LDS run — until round 4 checked against the C oracle only.
 Integers bit-exact; pi, theta_w, D to 1e-9 (JC pi 1e-6)."""
