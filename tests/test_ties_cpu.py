@@ -138,3 +138,27 @@ def test_exact_ties_need_a_column_of_eight_codons():
             x = sum(Fraction(b, 3 * k) for b, k in zip(nums, ks))
             assert (200 * x).denominator != 1 or (200 * x).numerator % 2 == 0
     assert (200 * (Fraction(2201) + Fraction(9, 24))).numerator % 2 == 1
+
+
+def test_replay_equals_the_c_oracles_column_order_sum_on_random_alignments():
+    """codon sets (numpy) -> stats.syn_sites_replay == the C oracle's count_syn, the same double, on 300 random coding
+    alignments: every alphabet of the random parity tests (gaps, N, IUPAC, stop codons by chance), 1 to 40 rows, lengths
+    that are not multiples of 3, mutation rates from 0 to 30 % (columns with many distinct codons)."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(2025)
+    alphabets = [b"ACGT", b"ACGT" * 4 + b"N-", b"ACGTRYKM-N", b"AC", b"ACGT" * 8 + b"acgtn?"]
+    n_many = 0
+    for trial in range(300):
+        n = int(rng.choice([1, 2, 3, 5, 8, 13, 20, 40]))
+        L = int(rng.choice([1, 2, 3, 4, 15, 16, 17, 99, 300, 301, 902]))
+        alpha = np.frombuffer(alphabets[trial % len(alphabets)], dtype=np.uint8)
+        base = rng.choice(alpha, size=L)
+        m = np.repeat(base[None, :], n, axis=0)
+        hit = rng.random((n, L)) < float(rng.choice([0.0, 0.01, 0.05, 0.3]))
+        m[hit] = rng.choice(alpha, size=int(hit.sum()))
+        sets = C.codon_sets_numpy(m)
+        n_many += int((np.bitwise_count(sets) >= 3).sum())
+        want = c_oracle.scan(m, cds=True)["count_syn"]
+        got = stats.syn_sites_replay(sets)
+        assert got == want, (trial, m.shape, repr(got), repr(want))
+    assert n_many > 500
