@@ -156,6 +156,9 @@ int64_t index_compact(uint8_t* text, uint64_t n_text, std::vector<pfa_fasta_row>
         sc.by_name.emplace(name, (uint32_t)cur);
       } else {   // a repeated name starts over but keeps its first position (dict)
         cur = it->second;
+        // (the lines of the earlier occurrence are dropped here, but the reference has decoded them like every other line)
+        if (sc.spans[cur].end > sc.spans[cur].first_line &&
+            !line_text_ok(text + sc.spans[cur].first_line, sc.spans[cur].end - sc.spans[cur].first_line)) sc.bad_text = true;
         rows[cur].seq_len = 0;
         rows[cur].seq_off = nx;
         sc.spans[cur] = IndexScratch::Span{nx, nx, 0u};

@@ -892,8 +892,12 @@ def g13():
     seq_bad[5] = seq_bad[5][:40] + b"\x80" + seq_bad[5][41:]            # a lone continuation byte inside the third record's sequence line
     head_bad = list(lines)
     head_bad[2] = head_bad[2] + b"\xff"                                   # ... or in a header line
+    # ... or in the sequence of a record that a later record of the same name replaces (readfasta keeps the last one, :234, :243)
+    dup_bad = list(lines)
+    dup_bad[3] = dup_bad[3][:10] + b"\xc3" + dup_bad[3][11:]          # a lead byte without its continuation, in the second record
+    dup_bad = dup_bad[:4] + [dup_bad[2], lines[3]] + dup_bad[4:]      # the same header again, with the clean sequence
     und = {}
-    for label, blob in (("in_sequence", b"\n".join(seq_bad)), ("in_header", b"\n".join(head_bad))):
+    for label, blob in (("in_sequence", b"\n".join(seq_bad)), ("in_header", b"\n".join(head_bad)), ("in_replaced_record", b"\n".join(dup_bad))):
         dd = os.path.join(tmp, "und_" + label)
         os.makedirs(dd)
         for fn, data in (("a_good.fa", good1), ("b_bad.fa", blob), ("c_good.fa", good3)):

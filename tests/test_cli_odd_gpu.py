@@ -140,9 +140,10 @@ def test_population_keys_at_their_edges(gpu, g13, tmp_path, monkeypatch, mode):
 
 
 @pytest.mark.parametrize("mode", list(MODES))
-@pytest.mark.parametrize("where", ["in_sequence", "in_header"])
+@pytest.mark.parametrize("where", ["in_sequence", "in_header", "in_replaced_record"])
 def test_undecodable_file_dies_where_the_reference_dies(gpu, g13, tmp_path, mode, where):
-    """A file that is not valid UTF-8 between two good ones (a lone 0x80 in a sequence line; a 0xFF in a header line): the
+    """A file that is not valid UTF-8 between two good ones (a lone 0x80 in a sequence line; a 0xFF in a header line; a lead byte
+    without continuation in the sequence of a record that a later record of the same name replaces): the
     reference prints the header and the rows of the files before it, then dies in its read loop with UnicodeDecodeError,
     exit code 1 (PolyFastA.py:239-240).  Same stdout, same --out file, same exit code, same last stderr line.  On standard
     input the reference's text layer takes the byte as a lone surrogate (UTF-8 mode: surrogateescape) and prints a row."""
