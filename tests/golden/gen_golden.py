@@ -916,6 +916,40 @@ def g13():
         runs["pipe"] = {"args": ["--pipe"], "stdout": p.stdout.decode(), "returncode": p.returncode, "stderr_tail": (p.stderr.decode().strip().splitlines() or [""])[-1]}
         und[label] = {"bad_file_hex": blob.hex(), "runs": runs}
     out["undecodable"] = {"layout": ["a_good.fa = example file1.fa", "b_bad.fa", "c_good.fa = example file3.fa"], **und}
+    # (e) the command line's way with paths: a trailing slash, a relative directory, names with blanks / non-ASCII letters / a leading
+    # dot, an empty directory, a path that does not exist, a directory after -f, empty standard input, -n without --pipe, -p without
+    # a value and with an empty one, --out with such names in its progress chatter
+    md = os.path.join(tmp, "misc")
+    d1 = os.path.join(md, "d1")
+    os.makedirs(d1)
+    os.makedirs(os.path.join(md, "empty"))
+    files = {"a.fa": open(f"{ex}/file1.fa").read(), "b file.fa": G3_TEXTS["gaps_iupac"], "\u00dcn\u00ef.fa": G3_TEXTS["lower_and_wrapped"],
+             ".hidden.fa": G3_TEXTS["plain"], "not_fasta.txt": G3_TEXTS["not_fasta"], "Z.fa": G3_TEXTS["crlf"]}
+    for fn, text in files.items():
+        with open(os.path.join(d1, fn), "w", newline="", encoding="utf-8") as fh:
+            fh.write(text)
+    f3 = open(f"{ex}/file3.fa", "rb").read()
+    runs = [("trailing_slash", ["-d", d1 + "/"], None, None),
+            ("cds_silent", ["-d", d1, "--cds", "-s"], None, None),
+            ("empty_dir", ["-d", os.path.join(md, "empty")], None, None),
+            ("missing_file", ["-f", os.path.join(d1, "a.fa"), os.path.join(md, "nope.fa")], None, None),
+            ("directory_as_file", ["-f", d1], None, None),
+            ("pipe_empty_stdin", ["--pipe"], b"", None),
+            ("pipe_pops_without_value", ["--pipe", "-n", "reg", "-p"], f3, None),
+            ("name_without_pipe", ["-f", os.path.join(d1, "a.fa"), "-n", "ignored"], None, None),
+            ("pops_empty_string", ["-f", os.path.join(d1, "a.fa"), "-p", ""], None, None),
+            ("relative_dir", ["-d", "d1"], None, md),
+            ("out_with_odd_names", ["-d", d1, "-o", os.path.join(md, "res.csv")], None, None)]
+    misc = {}
+    for name, args, stdin, cwd in runs:
+        p = subprocess.run([sys.executable, os.path.join(REF_DIR, "PolyFastA.py")] + args, input=stdin, capture_output=True, cwd=cwd,
+                           env={**os.environ, "PYTHONHASHSEED": "0", "PYTHONUTF8": "1"})
+        rec = {"args": [rel(a) for a in args], "cwd": None if cwd is None else rel(cwd + "/").rstrip("/"), "stdin_hex": None if stdin is None else stdin.hex(),
+               "stdout": rel(p.stdout.decode()), "returncode": p.returncode, "stderr_tail": rel((p.stderr.decode().strip().splitlines() or [""])[-1])}
+        if "-o" in args:
+            rec["file"] = open(args[args.index("-o") + 1]).read()
+        misc[name] = rec
+    out["cli_paths"] = {"files": files, "runs": misc}
     shutil.rmtree(tmp)
     dump("g13_cli_odd_inputs.json", out)
 

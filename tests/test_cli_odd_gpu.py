@@ -192,3 +192,31 @@ def test_two_ranks_die_at_an_undecodable_file_like_one_process(gpu, g13, tmp_pat
     same_lines(open(out).read(), want["stdout"], False, False)
     assert errs[0].strip().splitlines()[-1].replace("[rank0]: ", "") == want["stderr_tail"], errs[0][-1500:]      # (torch prefixes a rank's traceback)
     assert "UnicodeDecodeError" not in errs[1]
+
+
+def test_paths_as_the_reference_treats_them(gpu, g13, tmp_path):
+    """G13 `cli_paths`: a trailing slash after -d (the doubled slash shows in "is not FASTA!"), a relative directory, names with
+    blanks, non-ASCII letters and a leading dot (sorted as Python sorts the path strings), an empty directory, a path that does
+    not exist and a directory after -f (the reference's OSError after the rows before it), empty standard input, -n without
+    --pipe, -p without a value and with an empty one, --out with such names in its progress chatter: stdout, the --out file,
+    exit code and last stderr line, through real processes."""
+    cp = g13["cli_paths"]
+    d1 = tmp_path / "misc" / "d1"
+    d1.mkdir(parents=True)
+    (tmp_path / "misc" / "empty").mkdir()
+    for fn, text in cp["files"].items():
+        with open(d1 / fn, "w", newline="", encoding="utf-8") as fh:
+            fh.write(text)
+    sub = lambda t: t.replace("{TMP}", str(tmp_path))      # noqa: E731
+    for name, want in cp["runs"].items():
+        stdin = None if want["stdin_hex"] is None else bytes.fromhex(want["stdin_hex"])
+        e = dict(os.environ, PYTHONUTF8="1", PYTHONPATH=ROOT)
+        p = subprocess.run([sys.executable, "-m", "polyfasta_amd"] + [sub(a) for a in want["args"]], cwd=sub(want["cwd"]) if want["cwd"] else ROOT,
+                           capture_output=True, env=e, input=stdin if stdin is not None else None,
+                           stdin=subprocess.DEVNULL if stdin is None else None, timeout=600)
+        assert p.returncode == want["returncode"], (name, p.returncode, p.stderr.decode()[-1500:])
+        same_lines(p.stdout.decode(), sub(want["stdout"]), "--cds" in want["args"], False)
+        if want["returncode"]:
+            assert p.stderr.decode().strip().splitlines()[-1] == sub(want["stderr_tail"]), (name, p.stderr.decode()[-1500:])
+        if "file" in want:
+            same_lines(open(sub(want["args"][want["args"].index("-o") + 1])).read(), want["file"], False, False)
