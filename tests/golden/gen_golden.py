@@ -950,6 +950,44 @@ def g13():
             rec["file"] = open(args[args.index("-o") + 1]).read()
         misc[name] = rec
     out["cli_paths"] = {"files": files, "runs": misc}
+    # (f) more awkward file contents (bytes, written as they are): a byte-order mark in front of the first header (the reference reads
+    # utf-8, not utf-8-sig: the mark makes that line text before the first header and the record is lost), a NUL inside a sequence
+    # (a symbol like any other), a header of blanks only (rstrip leaves '': its lines are dropped, and a file that ENDS on it is not
+    # FASTA), a lone '>', a header without a line end, tabs behind a header and inside a sequence, a form feed between records
+    # (str.splitlines would split there; file iteration does not), thousands of sites on one line next to the same wrapped at 7
+    rnd = random.Random(131)
+    long_a = "".join(rnd.choice("ACGT") for _ in range(5000))
+    long_b = "".join(c if rnd.random() > 0.01 else rnd.choice("ACGT") for c in long_a)
+    more = {
+        "bom.fa": b"\xef\xbb\xbf>a\nACGT\n>b\nACGA\n>c\nACGG\n",
+        "nul_inside.fa": b">a\nAC\x00T\n>b\nACGT\n>c\nAC\x00T\n",
+        "blank_header.fa": b">a\nACGT\n>   \nTTTT\n>b\nACGA\n",
+        "ends_on_blank_header.fa": b">a\nACGT\n>b\nACGA\n> \t \nTTTT\n",
+        "lone_gt.fa": b">\n",
+        "header_no_eol.fa": b">a\nACGT\n>b",
+        "tabs.fa": b">a\t\t\nAC\tGT\n>b \t\nAC\tGA\n",
+        "form_feed.fa": b">a\nACGT\x0c>b\nACGA\n>c\nACGA\x0cT\n",
+        "long_lines.fa": (">a\n" + long_a + "\n>b\n" + "\n".join(long_b[i:i + 7] for i in range(0, 5000, 7)) + "\n").encode(),
+    }
+    dm = os.path.join(tmp, "more")
+    os.makedirs(dm)
+    for fn, blob in more.items():
+        with open(os.path.join(dm, fn), "wb") as fh:
+            fh.write(blob)
+    mruns = {}
+    for label, extra in (("plain", []), ("cds_jc", ["--cds", "--jc"])):
+        removed = []
+        while True:
+            p = ref_cli(["-d", dm] + extra)
+            if p.returncode == 0:
+                break
+            last = p.stdout.decode().rstrip("\n").split("\n")[-1]
+            nxt = sorted(os.listdir(dm))
+            victim = last.split(": ")[-1] if last.startswith("#") and last.split(": ")[-1] in nxt else nxt[nxt.index(last.split(",")[0]) + 1]
+            removed.append({"file": victim, "error": p.stderr.decode().strip().splitlines()[-1], "stdout_until_then": rel(p.stdout.decode())})
+            os.unlink(os.path.join(dm, victim))
+        mruns[label] = {"args": ["-d", "{TMP}/more"] + extra, "removed": removed, "stdout": rel(p.stdout.decode()), "returncode": 0}
+    out["more_texts"] = {"files_hex": {k: v.hex() for k, v in more.items()}, "runs": mruns}
     shutil.rmtree(tmp)
     dump("g13_cli_odd_inputs.json", out)
 

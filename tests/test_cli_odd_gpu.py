@@ -220,3 +220,23 @@ def test_paths_as_the_reference_treats_them(gpu, g13, tmp_path):
             assert p.stderr.decode().strip().splitlines()[-1] == sub(want["stderr_tail"]), (name, p.stderr.decode()[-1500:])
         if "file" in want:
             same_lines(open(sub(want["args"][want["args"].index("-o") + 1])).read(), want["file"], False, False)
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_more_awkward_file_contents(gpu, g13, tmp_path, monkeypatch, mode):
+    """G13 `more_texts`: a byte-order mark in front of the first header (that record is lost: the reference reads utf-8, not
+    utf-8-sig), a NUL inside a sequence, a header of blanks only in the middle and at the end, a lone '>', a header without a line
+    end, tabs behind a header and inside a sequence, a form feed between records (file iteration does not split there), 5 000
+    sites on one line next to the same wrapped at 7 — `-d` and `-d --cds --jc`, every line."""
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    mt = g13["more_texts"]
+    d = tmp_path / "more"
+    d.mkdir()
+    for fn, hx in mt["files_hex"].items():
+        (d / fn).write_bytes(bytes.fromhex(hx))
+    for label, want in mt["runs"].items():
+        assert not want["removed"]
+        rc, out = run_inproc([a.replace("{TMP}", str(tmp_path)) for a in want["args"]])
+        assert rc == 0
+        same_lines(out, want["stdout"].replace("{TMP}", str(tmp_path)), "--cds" in want["args"], "--jc" in want["args"])
