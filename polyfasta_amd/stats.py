@@ -125,15 +125,25 @@ def syn_tie_candidates(syn_num, n_sites):
     """Units whose synonymous-site count (or its complement, :167) sits on a two-decimal rounding boundary as far as double
     precision can tell: bool[n_units].  `syn_num`: uint32[n_units, 65]; `n_sites`: alignment length per unit.  The
     reference's accumulated rounding error is below (columns) x ulp(sum); anything within a generous multiple of that of
-    xxx.xx5 is replayed."""
+    xxx.xx5 is replayed.  Units whose columns all hold at most 7 distinct codons are at least 1 / (200 x 1260) = 4e-6 away
+    from any boundary (the sum is a multiple of 1/1260) and are not even looked at in floating point — unless they are so
+    long that the reference's own error could reach that far (millions of columns)."""
     import numpy as np
-    bins = np.asarray(syn_num, dtype=np.float64).reshape(-1, 65)
+    syn = np.asarray(syn_num).reshape(-1, 65)
+    n_sites = np.asarray(n_sites, dtype=np.float64)
+    cols = n_sites / 3.0 + 1.0
+    look = syn[:, 8:].any(axis=1) | (cols * np.spacing(np.maximum(n_sites, 1.0)) > 1e-8)
+    out = np.zeros(len(syn), dtype=bool)
+    if not look.any():
+        return out
+    idx = np.flatnonzero(look)
+    bins = syn[idx].astype(np.float64)
     k3 = 3.0 * np.arange(1, 65, dtype=np.float64)
     x = (bins[:, 1:] / k3).sum(axis=1)
     y = 100.0 * x
     d = np.abs(y - np.floor(y) - 0.5)
-    cols = np.asarray(n_sites, dtype=np.float64) / 3.0 + 1.0
-    return d < 1e-6 + 400.0 * cols * np.spacing(np.maximum(x, 1.0))
+    out[idx] = d < 1e-6 + 400.0 * cols[idx] * np.spacing(np.maximum(x, 1.0))
+    return out
 
 
 def syn_sites_replay(sets):
