@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Soak of the rounding-tie path through the command line: directories of coding alignments with planted columns of 8 / 16 distinct
+codons (so that a good share of the rows sits on a two-decimal tie of sites_S), `-d DIR --cds [--jc] [-p pop1,pop2]`, every row
+against the checker (the C oracle's integers, its count_syn accumulated in column order like the reference's, the oracle's own
+finishing math) — sites_S / sites_N as printed text.  usage: tools/tie_soak.py [seconds [first_seed]]"""
+import io
+import os
+import shutil
+import sys
+import tempfile
+import time
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from oracle import c_oracle  # noqa: E402
+from oracle import polyfasta_oracle as orc  # noqa: E402
+from polyfasta_amd import cli, stats, synth  # noqa: E402
+from tests import _cases as C  # noqa: E402
+
+CODONS = ["GCT", "GCC", "AAA", "AAG", "CTA", "TTA", "GAT", "CGA", "AGA", "TCT", "ACG", "GGG", "CAT", "ATT", "TGG", "GTA", "TAA", "CCC"]
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+t_end = time.time() + budget
+rows_checked = ties = dirs = 0
+while time.time() < t_end:
+    seed += 1
+    rng = np.random.default_rng(seed)
+    d = tempfile.mkdtemp(prefix="pfa_tie_soak_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        pops = bool(seed % 2)
+        jc = bool((seed // 2) % 2)
+        n_files = int(rng.integers(8, 72))
+        N = int(rng.choice([16, 50, 64, 100, 200]))
+        L = int(rng.choice([999, 3000, 3001, 9000]))
+        p = synth.make_params(N, float(rng.choice([0.005, 0.01, 0.03])))
+        hdr = synth.headers_for(N, 2 if pops else 0)
+        mats = []
+        for i in range(n_files):
+            m = synth.synth_alignment(seed, i, L, p, coding=True)
+            for _ in range(int(rng.integers(0, 4))):
+                k = int(rng.choice([8, 8, 8, 16]))
+                cods = [CODONS[j] for j in rng.permutation(len(CODONS))[:k]]
+                rows = None if not pops or rng.random() < 0.3 else np.arange(int(rng.integers(0, 2)), N, 2)
+                m = synth.plant_codons(m, int(rng.integers(0, L // 3)), cods, rows)
+            if rng.random() < 0.2:
+                m = synth.inject_symbols(m, seed * 1000 + i, 0.001, b"-N")
+            mats.append(m)
+            with open(os.path.join(d, f"t{i:03d}.fa"), "w") as fh:
+                fh.write(synth.to_fasta_text(hdr, m))
+        argv = ["-d", d, "-s", "--cds"] + (["--jc"] if jc else []) + (["-p", "pop1,pop2"] if pops else [])
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            assert cli.main(argv) == 0
+        got = [ln for ln in buf.getvalue().split("\n") if ln and not ln.startswith("#")]
+        want = []
+        for i, m in enumerate(mats):
+            for key in (["pop1", "pop2"] if pops else [None]):
+                rows = None if key is None else np.array([r for r, h in enumerate(hdr) if key in h], dtype=np.uint32)
+                o = c_oracle.scan(m, rows=rows, cds=True)
+                n = N if rows is None else len(rows)
+                want.append(orc.row_from_counts(f"t{i:03d}.fa", key or "NA", n, L, o, True, jc))
+                y = 100.0 * o["count_syn"]
+                ties += int(abs(y - int(y) - 0.5) < 1e-6)
+        assert len(got) == len(want), (seed, len(got), len(want))
+        for a, b in zip(got, want):
+            assert a.split(",")[:3] == b.split(",")[:3] and C.row_matches(a, b, True, jc) is None, (seed, argv, a, b)
+        rows_checked += len(want)
+        dirs += 1
+        if dirs % 10 == 0:
+            print(f"seed {seed}: {dirs} directories, {rows_checked} rows identical, {ties} of them on a rounding tie", flush=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+print(f"tie soak: {rows_checked} coding rows over {dirs} directories (seeds {first + 1} .. {seed}) identical to the checker, sites_S / sites_N as text; {ties} rows on a two-decimal rounding tie")
