@@ -208,3 +208,68 @@ def to_fasta_text(headers, matrix: np.ndarray, wrap: int = 0, newline: str = "\n
         else:
             parts.append(seq + newline)
     return "".join(parts)
+
+
+MIXED_MODES = ([], ["--cds"], ["--cds", "--jc"], ["--jc"])      # (the reference's own -p dies on every input under Python 3: G6 / G13 pin it per key)
+
+
+def mixed_directory(seed: int):
+    """A directory of small, awkward FASTA files and the flags to run on it: (dict file name -> bytes, list of flags).  For the
+    randomised command-line fixtures (tests/golden G14: the reference's transcript is frozen per seed, the files are made again
+    from the seed).  Per file: 1 to 30 sequences of 1 to 1 001 sites around a random consensus; then one of: as is, lower case
+    in some rows, other symbols (N - n R Y * ?), unequal lengths, non-ASCII characters at one site, no header at all, blank
+    lines and trailing blanks, a repeated header, a header with a description, a byte that is not UTF-8 (seldom).  Line ends
+    LF / CRLF / CR, sequences whole or wrapped at 60 / 7 characters."""
+    rng = np.random.default_rng([int(seed), 14])
+    flags = list(MIXED_MODES[seed % len(MIXED_MODES)])
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    files = {}
+    for i in range(int(rng.integers(3, 25))):
+        n = int(rng.choice([1, 2, 2, 3, 4, 7, 12, 30]))
+        L = int(rng.choice([1, 2, 3, 5, 6, 63, 64, 65, 127, 128, 129, 255, 256, 257, 600, 1001]))
+        base = rng.choice(acgt, size=L)
+        seqs = []
+        for r in range(n):
+            s = base.copy()
+            k = int(rng.integers(0, L // 20 + 2))
+            if k:
+                s[rng.integers(0, L, size=k)] = rng.choice(acgt, size=k)
+            seqs.append(s.tobytes().decode())
+        heads = [f"s{r}_pop{1 + r % 2}" for r in range(n)]
+        kind = int(rng.integers(0, 12))
+        if kind == 1:
+            seqs = [x.lower() if rng.random() < 0.5 else x for x in seqs]
+        elif kind == 2:
+            for r in range(n):
+                if rng.random() < 0.5:
+                    j = int(rng.integers(0, L))
+                    seqs[r] = seqs[r][:j] + str(rng.choice(list("N-nRY*?"))) + seqs[r][j + 1:]
+        elif kind == 3 and L > 3 and n > 1:
+            seqs[-1] = seqs[-1][:-1]
+        elif kind == 4:
+            j = int(rng.integers(0, L))
+            for r in range(n):
+                if rng.random() < 0.5:
+                    seqs[r] = seqs[r][:j] + str(rng.choice(list("éÉñЖ€"))) + seqs[r][j + 1:]
+        elif kind == 6 and n > 1:
+            heads[-1] = heads[0]
+        elif kind == 7:
+            heads = [h + " sample " + str(r) + ("  " if r % 2 else "") for r, h in enumerate(heads)]
+        eol = str(rng.choice(["\n", "\n", "\n", "\r\n", "\r"]))
+        wrap = int(rng.choice([0, 0, 60, 7]))
+        if kind == 5:
+            text = "no header here" + eol + seqs[0] + eol
+        else:
+            text = ""
+            for r, x in enumerate(seqs):
+                body = eol.join(x[k:k + wrap] for k in range(0, len(x), wrap)) if wrap else x
+                if kind == 8:
+                    body = body + "  " + eol
+                text += f">{heads[r]}{eol}{body}{eol}"
+            if kind == 8:
+                text = eol + text + eol + eol
+        blob = text.encode("utf-8")
+        if kind == 9 and rng.random() < 0.15:
+            blob = blob[:len(blob) // 2] + b"\xff" + blob[len(blob) // 2:]
+        files[f"f{i:03d}.fa"] = blob
+    return files, flags

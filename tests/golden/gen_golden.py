@@ -18,7 +18,8 @@ FASTA syntax, G4 exhaustive codon-set tables, G5 coding alignments, G6
 populations, G7 command-line transcripts, G8 the BASELINE.json configurations at their full sizes, G9 sequences
 with non-ASCII characters, G10 units of hundreds to 2^20 rows, G11 a directory entry that cannot be read, G12 coding
 alignments whose synonymous-site count is a two-decimal rounding tie, G13 odd inputs through the command line (the G3 texts
-as a directory, population-key edges, the same path twice, a file that is not valid UTF-8).
+as a directory, population-key edges, the same path twice, a file that is not valid UTF-8), G14 random directories of small
+awkward files through the command line in four flag combinations.
 """
 import os
 import sys
@@ -992,7 +993,52 @@ def g13():
     dump("g13_cli_odd_inputs.json", out)
 
 
+# ------------------------------------------------------- G14 random directories through the command line
+G14_SEEDS = list(range(1, 49))
+
+
+def g14():
+    """The reference's transcript for 48 random directories of small awkward files (polyfasta_amd.synth.mixed_directory: the
+    files are made again from the seed, only the transcript is frozen): `-d DIR -s` with the seed's flags (plain, --jc, --cds,
+    --cds --jc; the reference's -p dies on every input under Python 3, G6 and G13 pin populations per key) — stdout, exit code, and the last line of stderr where the reference dies (a file that is not
+    UTF-8, a coding alignment whose variable site falls on a zero site count: the rows before it are part of the transcript).
+    A directory the reference dies on is run again without the file it died on, until it gets through: every file is either in
+    a transcript that ends well or named as a victim."""
+    cases = []
+    for seed in G14_SEEDS:
+        files, flags = synth.mixed_directory(seed)
+        tmp = tempfile.mkdtemp()
+        d = os.path.join(tmp, "d")
+        os.makedirs(d)
+        for name, blob in files.items():
+            with open(os.path.join(d, name), "wb") as fh:
+                fh.write(blob)
+        runs, removed = [], []
+        while True:
+            p = ref_cli(["-d", d, "-s"] + flags)
+            out = p.stdout.decode()
+            run = {"removed": list(removed), "returncode": p.returncode, "stdout": out.replace(tmp + "/", "{TMP}/")}
+            runs.append(run)
+            if p.returncode == 0:
+                break
+            run["stderr_tail"] = p.stderr.decode().strip().splitlines()[-1]
+            # the file it died on: the one after the last file named in stdout
+            names = sorted(os.listdir(d))
+            seen = [ln.split(",")[0] if not ln.startswith("#") else ln.rsplit(": ", 1)[-1].rsplit(" ", 1)[-1] for ln in out.splitlines() if ln]
+            seen = [x for x in seen if x in names]
+            victim = names[names.index(seen[-1]) + 1] if seen else names[0]
+            run["victim"] = victim
+            removed.append(victim)
+            os.unlink(os.path.join(d, victim))
+            assert len(removed) < len(files)
+        shutil.rmtree(tmp)
+        cases.append({"seed": seed, "flags": flags, "n_files": len(files),
+                      "files_sha1": hashlib.sha1(b"".join(files[k] for k in sorted(files))).hexdigest(), "runs": runs})
+        print(f"g14 seed {seed}: {len(files)} files, flags {flags}, {len(runs)} run(s), died on {removed}", flush=True)
+    dump("g14_random_directories.json", {"cases": cases})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()

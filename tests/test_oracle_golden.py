@@ -291,3 +291,59 @@ def test_rounding_ties_g12():
                 assert got.split(",")[:3] == k["row"].split(",")[:3], (g, key, got, k["row"])
                 n_py += 1
     assert n_py == 6
+
+
+def test_random_directories_g14(tmp_path):
+    """G14: the reference's command-line transcripts of 48 random directories of small awkward files.  The generator still makes
+    the same files (their hash is frozen with the transcript), and the Python oracle — its reader on each file, its row or the
+    comment line the reference prints instead — gives every line of every transcript that ends well, and of the ones that do
+    not, every line up to the file the reference died on."""
+    import hashlib
+    from polyfasta_amd import synth
+    g14 = C.load("g14_random_directories.json")
+    n_rows = n_dead = 0
+    for case in g14["cases"]:
+        files, flags = synth.mixed_directory(case["seed"])
+        assert flags == case["flags"] and len(files) == case["n_files"]
+        assert hashlib.sha1(b"".join(files[k] for k in sorted(files))).hexdigest() == case["files_sha1"], case["seed"]
+        cds, jc = "--cds" in flags, "--jc" in flags
+        d = tmp_path / f"s{case['seed']}" / "d"
+        d.mkdir(parents=True)
+        for name, blob in files.items():
+            (d / name).write_bytes(blob)
+        for run in case["runs"]:
+            want = [ln for ln in run["stdout"].replace("{TMP}", str(d.parent)).split("\n") if ln]
+            got = []
+            for name in sorted(files):
+                if name in run["removed"]:
+                    continue
+                if name == run.get("victim"):
+                    with pytest.raises(UnicodeDecodeError):
+                        orc.readfasta(str(d / name))
+                    n_dead += 1
+                    break
+                # the reference hands `-d DIR` + name to readfasta as typed: DIR/name
+                dd = orc.readfasta(str(d / name))
+                if dd is None:
+                    got.append(f"# file {d / name} is not FASTA!")
+                    continue
+                lens = {len(x) for x in dd.values()}
+                if len(lens) != 1:
+                    got.append(f"# Sequences do not have the same length: {name}")
+                    continue
+                L = lens.pop()
+                if cds and L % 3:
+                    got.append(f"# CDS sequence length is not a multiple of 3: {name}")
+                got.append(orc.result_row(dd, L, cds, name, "NA", jc))
+                # the C oracle on the same alignment as a byte matrix, finished by the integer-summary formatter
+                from polyfasta_amd import fasta
+                o = c_oracle.scan(fasta.matrix_from_dict(dd), cds=cds)
+                C.rows_close(orc.row_from_counts(name, "NA", len(dd), L, o, cds, jc), got[-1], rel=1e-12, rel_jc=1e-9, jc=jc)
+            assert len(got) == len(want), (case["seed"], run["removed"], got[-2:], want[-2:])
+            for a, b in zip(got, want):
+                if b.startswith("#"):
+                    assert a == b
+                else:
+                    C.rows_close(a, b, rel=1e-12, rel_jc=1e-9, jc=jc)
+                    n_rows += 1
+    assert n_rows > 600 and n_dead >= 6
