@@ -311,6 +311,34 @@ def getvarCDSsites(d, seqlen):
     return count_syn, syn, non, nstops, missing
 
 
+def count_syn_outcomes(d, seqlen, trials=200, seed=0):
+    """What the reference PRINTS for sites_S / sites_N over its own run-to-run freedom: ref:292 makes each codon column a
+    list(set(...)) of strings and ref:307 sums syncodfreq over it with sum([...]) — in the set's iteration order, which
+    Python's randomised string hashing draws anew in every run.  Restated with the order drawn explicitly (a shuffle per
+    column and trial): Counter {(round(ssites, 2), round(nsites, 2)): trials}.  One entry wherever the reference is
+    identical to itself; two on some two-decimal ties (tests/golden G12 `order_dependent`)."""
+    import random
+    from collections import Counter
+    rnd = random.Random(seed)
+    names = list(d)
+    cols, missing = [], 0
+    for cp in range(0, seqlen, 3):
+        clean = sorted(c for c in set(d[name][cp:cp + 3] for name in names) if _is_clean(c))
+        if clean:
+            cols.append([syncodfreq(c) for c in clean])
+        else:
+            missing += 3
+    out = Counter()
+    for _ in range(trials):
+        count_syn = 0.0
+        for vals in cols:
+            if len(vals) > 2:
+                rnd.shuffle(vals)
+            count_syn += sum(vals) / len(vals)
+        out[(round(count_syn, 2), round((seqlen - missing) - count_syn, 2))] += 1
+    return out
+
+
 # --------------------------------------------------------------------------
 # Row assembly (ref:147-198, the `no_header` closure) as pure functions
 # --------------------------------------------------------------------------

@@ -177,7 +177,7 @@ def codon_sets(plan_handle, unit: int, n_sites: int, d_bases=None) -> np.ndarray
 def resolve_syn_ties(plan_handle, syn_num, n_sites, d_bases=None, every=None):
     """Per unit NaN, or — for a unit whose synonymous-site count sits on a two-decimal rounding tie — that count as the
     reference itself accumulates it, column by column in floating point (PolyFastA.py:307), replayed from the unit's codon
-    sets (stats.syn_sites_replay).  A handful of units in a thousand; everything else prints the same digits either way.
+    sets (stats.syn_sites_replay / syn_sites_most_likely).  A handful of units in a thousand; everything else prints the same digits either way.
     Call it while the matrices of the plan's run are still on the card.  `every`: bool per unit — replay these whatever
     their bins say (the API mirror returns the reference's count_syn itself)."""
     from . import stats
@@ -185,11 +185,13 @@ def resolve_syn_ties(plan_handle, syn_num, n_sites, d_bases=None, every=None):
     out = np.full(len(n_sites), np.nan, dtype=np.float64)
     if syn_num is None or len(out) == 0:
         return out
-    pick = stats.syn_tie_candidates(syn_num, n_sites)
-    if every is not None:
-        pick = pick | np.asarray(every, dtype=bool)
+    tie = stats.syn_tie_candidates(syn_num, n_sites)
+    pick = tie if every is None else tie | np.asarray(every, dtype=bool)
     for i in np.flatnonzero(pick).tolist():
-        out[i] = stats.syn_sites_replay(codon_sets(plan_handle, i, int(n_sites[i]), d_bases))
+        sets = codon_sets(plan_handle, i, int(n_sites[i]), d_bases)
+        # on a tie the reference's own digit can hang on its interpreter's hash seed (the summation order of a column of three
+        # or more codons): then the digits it prints most often (stats.syn_sites_most_likely); the same value otherwise
+        out[i] = stats.syn_sites_most_likely(sets, int(n_sites[i])) if tie[i] else stats.syn_sites_replay(sets)
     return out
 
 

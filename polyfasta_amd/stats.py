@@ -146,22 +146,14 @@ def syn_tie_candidates(syn_num, n_sites):
     return out
 
 
-def syn_sites_replay(sets):
-    """count_syn exactly as getvarCDSsites accumulates it (PolyFastA.py:307), from the set of distinct clean codons of every
-    codon column in column order (`sets`: uint64[ceil(L / 3)], 0 = no clean codon: the column adds nothing, :301-305).
-    Per column sum([syncodfreq(c) ...]) / len(...) — Python's left-to-right float sum starting from int 0 — then added
-    to the running total.  Columns with three or more codons are summed in ascending codon order (the reference walks
-    a Python set of strings there: its order, and with it the last bit of such a term, follows the interpreter's hash
-    seed)."""
+def _replay_terms(s):
+    """the per-column terms sum([syncodfreq(c) ...]) / len(...) of the non-empty codon sets `s` (uint64[...]); columns with three
+    or more codons summed in ascending codon order"""
     import numpy as np
     global _SYN_FLOAT
     if _SYN_FLOAT is None:
         _SYN_FLOAT = _syn_float_by_codon()
     F = _SYN_FLOAT
-    s = np.ascontiguousarray(sets, dtype=np.uint64)
-    s = s[s != 0]
-    if len(s) == 0:
-        return 0.0
     k = np.bitwise_count(s).astype(np.int64)
     one = np.uint64(1)
     low = s & (~s + one)                                   # lowest set bit
@@ -178,4 +170,102 @@ def syn_sites_replay(sets):
         for c in cods:
             t = t + float(F[c])
         terms[i] = t / len(cods)
-    return float(np.add.accumulate(terms)[-1])            # sequential: r[i] = r[i-1] + terms[i]
+    return terms
+
+
+def syn_sites_replay(sets):
+    """count_syn exactly as getvarCDSsites accumulates it (PolyFastA.py:307), from the set of distinct clean codons of every
+    codon column in column order (`sets`: uint64[ceil(L / 3)], 0 = no clean codon: the column adds nothing, :301-305).
+    Per column sum([syncodfreq(c) ...]) / len(...) — Python's left-to-right float sum starting from int 0 — then added
+    to the running total.  Columns with three or more codons are summed in ascending codon order (the reference walks
+    a Python set of strings there: its order, and with it the last bit of such a term, follows the interpreter's hash
+    seed; syn_sites_most_likely below for the alignments where that reaches the printed digits)."""
+    import numpy as np
+    s = np.ascontiguousarray(sets, dtype=np.uint64)
+    s = s[s != 0]
+    if len(s) == 0:
+        return 0.0
+    return float(np.add.accumulate(_replay_terms(s))[-1])            # sequential: r[i] = r[i-1] + terms[i]
+
+
+# ------------------------------------------------------------------ where the reference's own digit hangs on its hash seed
+# A codon column with three or more distinct codons is summed in the iteration order of a Python set of strings
+# (PolyFastA.py:292-307: list(set(...)), then sum([...]) / len): under the interpreter's default, randomised string hashing,
+# an order drawn anew by every run.  Most multisets of synonymous-site fractions give the same float in every order; some do not
+# (1/3 + 2/3 + 1. + ... over eight codons: 2.9999999999999996, 3.0 or 3.0000000000000004), and when the alignment's exact
+# sum is a two-decimal tie, the reference itself prints x.37 in some runs and x.38 in others (tests/golden G12
+# `order_dependent`: the reference under 40 hash seeds).  There is no single answer to be identical to; this implementation
+# prints the digits the reference prints MOST OFTEN: the column terms' distributions over summation orders (every order for up to
+# seven codons, 4 096 drawn ones above), 512 draws of the whole alignment accumulated in column order like the reference, the
+# commonest printed (sites_S, sites_N) pair.  Deterministic: the draws are seeded by the codon sets themselves.
+_TERM_POOLS = {}
+
+
+def _term_pool(vals):
+    """Every value sum(order) / k takes over the orders of the float terms `vals` (a sorted tuple), with the frequencies of
+    the orders: None when every order gives the same float, else float64[...] to draw from uniformly."""
+    import itertools
+    import numpy as np
+    pool = _TERM_POOLS.get(vals)
+    if pool is None and vals not in _TERM_POOLS:
+        k = len(vals)
+        if k <= 7:
+            perms = np.array(list(itertools.permutations(vals)), dtype=np.float64)
+        else:
+            import zlib
+            rng = np.random.default_rng(zlib.crc32(np.array(vals, dtype=np.float64).tobytes()))
+            perms = rng.permuted(np.tile(np.array(vals, dtype=np.float64), (4096, 1)), axis=1)
+        sums = np.add.accumulate(perms, axis=1)[:, -1] / k          # left to right, like sum() from 0
+        pool = None if (sums == sums[0]).all() else sums
+        _TERM_POOLS[vals] = pool
+    return pool
+
+
+def syn_sites_most_likely(sets, n_sites, draws=512):
+    """count_syn of an alignment on a two-decimal tie, as the reference most often has it: `sets` as for syn_sites_replay (the
+    full array, zeros included: they are the columns PolyFastA.py:302 counts as missing), `n_sites` the alignment length.
+    Equal to syn_sites_replay(sets) bit for bit when no column's term depends on its summation order."""
+    import zlib
+    import numpy as np
+    global _SYN_FLOAT
+    if _SYN_FLOAT is None:
+        _SYN_FLOAT = _syn_float_by_codon()
+    F = _SYN_FLOAT
+    s_all = np.ascontiguousarray(sets, dtype=np.uint64)
+    s = s_all[s_all != 0]
+    base = syn_sites_replay(s_all)
+    if len(s) == 0:
+        return base
+    k = np.bitwise_count(s)
+    loose = []
+    for i in np.flatnonzero(k >= 3).tolist():
+        m = int(s[i])
+        vals = tuple(sorted(float(F[c]) for c in range(64) if (m >> c) & 1))
+        pool = _term_pool(vals)
+        if pool is not None:
+            loose.append((i, pool))
+    if not loose:
+        return base
+    terms = _replay_terms(s)      # the ascending-order terms of every column; the loose columns are redrawn per draw
+    rng = np.random.default_rng(zlib.crc32(s_all.tobytes()))
+    # only the columns from the first loose one on differ between draws: the prefix is summed once
+    first = loose[0][0]
+    draws = max(64, min(int(draws), 8_000_000 // max(1, len(terms) - first)))      # bounded memory for alignments of millions of sites
+    head = float(np.add.accumulate(terms[:first])[-1]) if first else 0.0
+    T = np.tile(terms[first:], (draws, 1))
+    for i, pool in loose:
+        T[:, i - first] = pool[rng.integers(0, len(pool), size=draws)]
+    T[:, 0] = head + T[:, 0] if first else T[:, 0]
+    totals = np.add.accumulate(T, axis=1)[:, -1]
+    A = int(n_sites) - 3 * int((s_all == 0).sum())
+    vals, counts = np.unique(totals, return_counts=True)
+    by_pair = {}
+    for v, c in zip(vals.tolist(), counts.tolist()):
+        pair = (round(v, 2), round(A - v, 2))
+        e = by_pair.setdefault(pair, [0, 0, v])
+        e[0] += c
+        if c > e[1]:
+            e[1], e[2] = c, v
+    base_pair = (round(base, 2), round(A - base, 2))
+    best = max(by_pair.items(), key=lambda kv: (kv[1][0], kv[0] == base_pair, -kv[0][0]))
+    return base if best[0] == base_pair else float(best[1][2])

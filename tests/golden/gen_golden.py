@@ -19,7 +19,8 @@ populations, G7 command-line transcripts, G8 the BASELINE.json configurations at
 with non-ASCII characters, G10 units of hundreds to 2^20 rows, G11 a directory entry that cannot be read, G12 coding
 alignments whose synonymous-site count is a two-decimal rounding tie, G13 odd inputs through the command line (the G3 texts
 as a directory, population-key edges, the same path twice, a file that is not valid UTF-8), G14 random directories of small
-awkward files through the command line in four flag combinations.
+awkward files through the command line in four flag combinations, G15 two-decimal ties whose printed digit follows the
+reference's own hash seed (its output under 60 seeds).
 """
 import os
 import sys
@@ -994,11 +995,11 @@ def g13():
 
 
 # ------------------------------------------------------- G14 random directories through the command line
-G14_SEEDS = list(range(1, 49))
+G14_SEEDS = list(range(1, 49)) + [590]      # 590: the directory in which tools/g14_explore.py ran into a tie the reference itself does not fix (G15)
 
 
 def g14():
-    """The reference's transcript for 48 random directories of small awkward files (polyfasta_amd.synth.mixed_directory: the
+    """The reference's transcript for 49 random directories of small awkward files (polyfasta_amd.synth.mixed_directory: the
     files are made again from the seed, only the transcript is frozen): `-d DIR -s` with the seed's flags (plain, --jc, --cds,
     --cds --jc; the reference's -p dies on every input under Python 3, G6 and G13 pin populations per key) — stdout, exit code, and the last line of stderr where the reference dies (a file that is not
     UTF-8, a coding alignment whose variable site falls on a zero site count: the rows before it are part of the transcript).
@@ -1038,7 +1039,66 @@ def g14():
     dump("g14_random_directories.json", {"cases": cases})
 
 
+# ------------------------------------------------------- G15 two-decimal ties on which the reference disagrees with itself
+def g15():
+    """Coding alignments on a two-decimal tie of sites_S whose printed digit the reference itself does not fix: a codon column of
+    three or more codons is summed in the iteration order of a Python set of strings (PolyFastA.py:292, :307), which the
+    interpreter's randomised string hashing draws anew in every run.  Frozen: the alignment (literal text) and what the reference's
+    command line printed for sites_S / sites_N under PYTHONHASHSEED = 0 .. 59, as counts per printed pair.  Kept are cases with
+    a clear majority (at least 60 %): this implementation prints the majority's digits (stats.syn_sites_most_likely).
+    The first case is the one a random directory ran into (synth.mixed_directory(590), f002.fa: one codon column, eight codons,
+    the sum 3/8); the others are searched: 30 sequences around a random consensus, one column planted with eight random codons."""
+    from collections import Counter
+    texts = [("mixed_directory_590_f002", synth.mixed_directory(590)[0]["f002.fa"].decode())]
+    rng = np.random.default_rng(15)
+    acgt = "ACGT"
+    tried = 0
+    while len(texts) < 9 and tried < 4000:
+        tried += 1
+        n, L = 30, int(rng.choice([3, 6, 30, 60, 300]))
+        base = "".join(acgt[i] for i in rng.integers(0, 4, size=L))
+        rows = []
+        for r in range(n):
+            x = list(base)
+            for j in rng.integers(0, L, size=int(rng.integers(0, L // 20 + 2))).tolist():
+                x[j] = acgt[int(rng.integers(0, 4))]
+            rows.append(x)
+        col = 3 * int(rng.integers(0, L // 3))
+        cods = ["".join(acgt[i] for i in c) for c in rng.choice(4, size=(8, 3)).tolist()]
+        if len(set(cods)) != 8:
+            continue
+        for r in range(n):
+            rows[r][col:col + 3] = list(cods[r % 8])
+        d = {f"s{r}": "".join(x) for r, x in enumerate(rows)}
+        cs = ref.getvarCDSsites(d, L)[0]
+        lo, hi = count_syn_range(d, L)
+        if not is_tie(cs) or round(lo, 2) == round(hi, 2):
+            continue
+        texts.append((f"searched_{tried}_L{L}", "".join(f">{h}\n{x}\n" for h, x in d.items())))
+    cases = []
+    tmp = tempfile.mkdtemp()
+    for label, text in texts:
+        path = os.path.join(tmp, "x.fa")
+        with open(path, "w") as fh:
+            fh.write(text)
+        seen = Counter()
+        for hs in range(60):
+            p = subprocess.run([sys.executable, os.path.join(REF_DIR, "PolyFastA.py"), "-f", path, "-s", "--cds"], capture_output=True,
+                               env={**os.environ, "PYTHONHASHSEED": str(hs), "PYTHONUTF8": "1"})
+            assert p.returncode == 0, p.stderr.decode()
+            row = [ln for ln in p.stdout.decode().splitlines() if ln and not ln.startswith("#")][-1].split(",")
+            seen[(row[1], row[2])] += 1
+        top, cnt = seen.most_common(1)[0]
+        print(f"  G15 {label}: {dict(seen)}", flush=True)
+        if len(seen) < 2 or cnt < 36:
+            continue
+        cases.append({"label": label, "text": text, "printed": [[a, b, c] for (a, b), c in sorted(seen.items())], "most_often": list(top)})
+    shutil.rmtree(tmp)
+    assert len(cases) >= 5 and cases[0]["label"].startswith("mixed_directory")
+    dump("g15_hash_seed_ties.json", {"hash_seeds": 60, "cases": cases})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()

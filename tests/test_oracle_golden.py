@@ -294,14 +294,14 @@ def test_rounding_ties_g12():
 
 
 def test_random_directories_g14(tmp_path):
-    """G14: the reference's command-line transcripts of 48 random directories of small awkward files.  The generator still makes
+    """G14: the reference's command-line transcripts of 49 random directories of small awkward files.  The generator still makes
     the same files (their hash is frozen with the transcript), and the Python oracle — its reader on each file, its row or the
     comment line the reference prints instead — gives every line of every transcript that ends well, and of the ones that do
     not, every line up to the file the reference died on."""
     import hashlib
     from polyfasta_amd import synth
     g14 = C.load("g14_random_directories.json")
-    n_rows = n_dead = 0
+    n_rows = n_dead = n_unfixed = 0
     for case in g14["cases"]:
         files, flags = synth.mixed_directory(case["seed"])
         assert flags == case["flags"] and len(files) == case["n_files"]
@@ -334,11 +334,23 @@ def test_random_directories_g14(tmp_path):
                 L = lens.pop()
                 if cds and L % 3:
                     got.append(f"# CDS sequence length is not a multiple of 3: {name}")
-                got.append(orc.result_row(dd, L, cds, name, "NA", jc))
+                row = orc.result_row(dd, L, cds, name, "NA", jc)
                 # the C oracle on the same alignment as a byte matrix, finished by the integer-summary formatter
                 from polyfasta_amd import fasta
                 o = c_oracle.scan(fasta.matrix_from_dict(dd), cds=cds)
-                C.rows_close(orc.row_from_counts(name, "NA", len(dd), L, o, cds, jc), got[-1], rel=1e-12, rel_jc=1e-9, jc=jc)
+                crow = orc.row_from_counts(name, "NA", len(dd), L, o, cds, jc)
+                outcomes = orc.count_syn_outcomes(dd, L, trials=300, seed=14) if cds else {}
+                if len(outcomes) > 1:
+                    # a tie the reference itself does not fix (its digit follows its hash seed, G15; seed 590 holds one): the
+                    # frozen digits are one of the outcomes, the rest of the row is compared with them filled in
+                    ref_line = next(ln for ln in want if ln.startswith(name + ","))
+                    pair = ref_line.split(",")[1:3]
+                    assert (float(pair[0]), float(pair[1])) in outcomes, (name, pair, outcomes)
+                    row = ",".join(row.split(",")[:1] + pair + row.split(",")[3:])
+                    crow = ",".join(crow.split(",")[:1] + pair + crow.split(",")[3:])
+                    n_unfixed += 1
+                got.append(row)
+                C.rows_close(crow, row, rel=1e-12, rel_jc=1e-9, jc=jc)
             assert len(got) == len(want), (case["seed"], run["removed"], got[-2:], want[-2:])
             for a, b in zip(got, want):
                 if b.startswith("#"):
@@ -346,4 +358,4 @@ def test_random_directories_g14(tmp_path):
                 else:
                     C.rows_close(a, b, rel=1e-12, rel_jc=1e-9, jc=jc)
                     n_rows += 1
-    assert n_rows > 600 and n_dead >= 6
+    assert n_rows > 600 and n_dead >= 6 and n_unfixed >= 1

@@ -196,6 +196,39 @@ def test_replayed_count_equals_the_column_order_sum_on_random_units(gpu):
         out = scan.scan_batch(b, exact_syn=True)
         for i, (m, rows) in enumerate(units):
             want = c_oracle.scan(m, rows=rows, cds=True)["count_syn"]
-            assert float(out.sites_s[i]) == want, (plan_no, i, m.shape, repr(float(out.sites_s[i])), repr(want))
+            got = float(out.sites_s[i])
+            if got != want:
+                # only on a rounding tie whose digit the reference itself does not fix (G15): there the value it most often has
+                sub = m if rows is None else m[rows]
+                assert stats.syn_tie_candidates(C.syn_bins_numpy(sub)[None, :], [m.shape[1]])[0], (plan_no, i, m.shape, repr(got), repr(want))
+                assert got == stats.syn_sites_most_likely(C.codon_sets_numpy(sub), m.shape[1]) and abs(got - want) < 1e-12
             checked += 1
     assert checked == 400
+
+
+def test_ties_the_reference_does_not_fix_g15(gpu, tmp_path, monkeypatch):
+    """G15: on these alignments the reference's own sites_S digit follows its hash seed (its output under 60 seeds is frozen);
+    `-f`, `-d` in both ingest modes and the API mirror give the digits it printed most often."""
+    g15 = C.load("g15_hash_seed_ties.json")
+    d = tmp_path / "d"
+    d.mkdir()
+    for i, case in enumerate(g15["cases"]):
+        (d / f"t{i:02d}.fa").write_text(case["text"])
+        rc, out = run_cli(["-f", str(d / f"t{i:02d}.fa"), "-s", "--cds"])
+        assert rc == 0 and out.rstrip("\n").split("\n")[-1].split(",")[1:3] == case["most_often"], (case["label"], out)
+    for env in ({}, {"PFA_INGEST_NO_DIRECT": "1", "PFA_INGEST_SLOT_BYTES": "4096"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for flags in (["--cds"], ["--cds", "--jc"]):
+            rc, out = run_cli(["-d", str(d), "-s"] + flags)
+            rows = [ln.split(",") for ln in out.split("\n") if ln and not ln.startswith("#")]
+            assert rc == 0 and [r[1:3] for r in rows] == [c["most_often"] for c in g15["cases"]]
+    for case in g15["cases"]:
+        dd = {}
+        for ln in case["text"].split("\n"):
+            if ln.startswith(">"):
+                h = ln[1:]
+            elif ln:
+                dd[h] = ln
+        L = len(next(iter(dd.values())))
+        assert str(round(api.getvarCDSsites(dd, L)[0], 2)) == case["most_often"][0]

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Hunt for differences from the reference beyond the frozen G14 seeds.
+  make FIRST COUNT OUT.json   (build container: runs /root/reference/PolyFastA.py on synth.mixed_directory(seed) for COUNT seeds)
+  check IN.json               (GPU box: python -m polyfasta_amd on the same directories, both ingest modes, every line)
+The JSON is scratch (not a fixture); a seed that shows a difference belongs into tests/golden/gen_golden.py's G14_SEEDS."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from polyfasta_amd import synth  # noqa: E402
+
+
+def write_dir(top, files):
+    d = os.path.join(top, "d")
+    os.makedirs(d)
+    for name, blob in files.items():
+        with open(os.path.join(d, name), "wb") as fh:
+            fh.write(blob)
+    return d
+
+
+def make(first, count, out):
+    cases = []
+    for seed in range(first, first + count):
+        files, flags = synth.mixed_directory(seed)
+        top = tempfile.mkdtemp()
+        d = write_dir(top, files)
+        runs, removed = [], []
+        while True:
+            p = subprocess.run([sys.executable, "/root/reference/PolyFastA.py", "-d", d, "-s"] + flags, capture_output=True,
+                               env={**os.environ, "PYTHONHASHSEED": "0", "PYTHONUTF8": "1"})
+            o = p.stdout.decode()
+            run = {"removed": list(removed), "returncode": p.returncode, "stdout": o.replace(top + "/", "{TMP}/")}
+            runs.append(run)
+            if p.returncode == 0:
+                break
+            run["stderr_tail"] = p.stderr.decode().strip().splitlines()[-1]
+            names = sorted(os.listdir(d))
+            seen = [ln.split(",")[0] if not ln.startswith("#") else ln.rsplit(": ", 1)[-1].rsplit(" ", 1)[-1] for ln in o.splitlines() if ln]
+            seen = [x for x in seen if x in names]
+            victim = names[names.index(seen[-1]) + 1] if seen else names[0]
+            removed.append(victim)
+            os.unlink(os.path.join(d, victim))
+            if len(removed) >= len(files):
+                break
+        shutil.rmtree(top)
+        cases.append({"seed": seed, "flags": flags, "runs": runs})
+        if seed % 25 == 0:
+            print(f"seed {seed}", flush=True)
+    json.dump({"cases": cases}, open(out, "w"))
+
+
+def check(path):
+    from tests import _cases as C
+    from tests.test_cli_odd_gpu import MODES, run_inproc, run_proc
+    cases = json.load(open(path))["cases"]
+    bad = rows = 0
+    for mode, env in MODES.items():
+        for k in ("PFA_INGEST_NO_DIRECT", "PFA_INGEST_SLOT_BYTES"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        for case in cases:
+            files, flags = synth.mixed_directory(case["seed"])
+            cds, jc = "--cds" in flags, "--jc" in flags
+            top = tempfile.mkdtemp()
+            d = write_dir(top, files)
+            for run in case["runs"]:
+                for name in run["removed"]:
+                    if os.path.exists(os.path.join(d, name)):
+                        os.unlink(os.path.join(d, name))
+                want = run["stdout"].replace("{TMP}", top)
+                argv = ["-d", d, "-s"] + flags
+                if run["returncode"] == 0:
+                    try:
+                        rc, out = run_inproc(argv)
+                    except BaseException as e:      # noqa: BLE001
+                        rc, out = -1, f"{type(e).__name__}: {e}"
+                    tail = None
+                else:
+                    p = run_proc(argv, env=env)
+                    rc, out = p.returncode, p.stdout.decode()
+                    tail = p.stderr.decode().strip().splitlines()[-1] if p.stderr.strip() else ""
+                gl, wl = out.split("\n"), want.split("\n")
+                diff = None
+                if rc != run["returncode"]:
+                    diff = f"exit code {rc} != {run['returncode']}"
+                elif tail is not None and tail != run["stderr_tail"]:
+                    diff = f"stderr {tail!r} != {run['stderr_tail']!r}"
+                elif len(gl) != len(wl):
+                    diff = f"{len(gl)} lines != {len(wl)}"
+                else:
+                    for a, b in zip(gl, wl):
+                        if a != b and (b.startswith("#") or "," not in b or C.row_matches(a, b, cds, jc) is not None):
+                            diff = f"{a!r} != {b!r}"
+                            break
+                        rows += bool(b) and not b.startswith("#")
+                if diff:
+                    bad += 1
+                    print(f"DIFFERENCE seed {case['seed']} mode {mode} flags {flags} removed {run['removed']}: {diff}", flush=True)
+            shutil.rmtree(top)
+    print(f"g14_explore: {len(cases)} directories in {len(MODES)} ingest modes, {rows} rows compared, {bad} differences")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "make":
+        make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    else:
+        sys.exit(check(sys.argv[2]))
