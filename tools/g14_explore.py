@@ -58,8 +58,10 @@ def make(first, count, out):
 def check(path):
     from tests import _cases as C
     from tests.test_cli_odd_gpu import MODES, run_inproc, run_proc
+    from oracle import polyfasta_oracle as orc
     cases = json.load(open(path))["cases"]
     bad = rows = 0
+    unfixed = []
     for mode, env in MODES.items():
         for k in ("PFA_INGEST_NO_DIRECT", "PFA_INGEST_SLOT_BYTES"):
             os.environ.pop(k, None)
@@ -95,6 +97,16 @@ def check(path):
                     diff = f"{len(gl)} lines != {len(wl)}"
                 else:
                     for a, b in zip(gl, wl):
+                        if a != b and cds and not b.startswith("#") and a.split(",")[0] == b.split(",")[0] and a.split(",")[1:3] != b.split(",")[1:3]:
+                            # sites_S / sites_N differ: a tie on which the reference differs from itself (its digit follows its hash
+                            # seed, G15)?  Then both pairs are outcomes of the checker's restatement of that freedom; the product is
+                            # to print the commonest one, and the rest of the row must agree.
+                            dd = orc.readfasta(os.path.join(d, a.split(",")[0]))
+                            outs = orc.count_syn_outcomes(dd, len(next(iter(dd.values()))), trials=600, seed=1)
+                            pa, pb = tuple(float(x) for x in a.split(",")[1:3]), tuple(float(x) for x in b.split(",")[1:3])
+                            if pa in outs and pb in outs:
+                                unfixed.append((case["seed"], a.split(",")[0], pa, pb, dict(outs), max(outs, key=outs.get) == pa))
+                                b = ",".join(b.split(",")[:1] + a.split(",")[1:3] + b.split(",")[3:])
                         if a != b and (b.startswith("#") or "," not in b or C.row_matches(a, b, cds, jc) is not None):
                             diff = f"{a!r} != {b!r}"
                             break
@@ -103,7 +115,10 @@ def check(path):
                     bad += 1
                     print(f"DIFFERENCE seed {case['seed']} mode {mode} flags {flags} removed {run['removed']}: {diff}", flush=True)
             shutil.rmtree(top)
-    print(f"g14_explore: {len(cases)} directories in {len(MODES)} ingest modes, {rows} rows compared, {bad} differences")
+    for u in unfixed:
+        print(f"tie the reference does not fix: seed {u[0]} {u[1]}: printed {u[2]}, the reference under PYTHONHASHSEED=0 {u[3]}; the checker's outcomes {u[4]}; printed the commonest: {u[5]}")
+    bad += sum(1 for u in unfixed if not u[5])
+    print(f"g14_explore: {len(cases)} directories in {len(MODES)} ingest modes, {rows} rows compared, {bad} differences, {len(unfixed)} rows (both modes counted) on a tie the reference itself does not fix")
     return 1 if bad else 0
 
 
