@@ -213,7 +213,8 @@ def text_alignment_units(data, path, args, keys):
     its own — the scan only asks whether two rows hold the same symbol and whether a symbol is exactly A, C, G or T — and
     the matrix is scanned on the card as one small batch.  Returns (units, lines): units as (key index or PFA_NO_KEY,
     n_rows, n_sites, record, syn row, sfs list, sites_S override or None), lines as (sub-order, kind, text); or None when the file holds more
-    distinct characters than a byte has values (fasta.byte_codes) or no sites."""
+    distinct characters than a byte has values (fasta.byte_codes).  Sequences of no sites at all are an alignment like any other
+    (a piped file with bare-CR line ends is one header line: one sequence, zero sites)."""
     from ._lib import PFA_NO_KEY
     name = path.split("/")[-1]
     if data is None:
@@ -223,7 +224,7 @@ def text_alignment_units(data, path, args, keys):
         return [], [(0, "comment", f"# Sequences do not have the same length: {name}")]                # :135-140
     seqlen = len(seqs[0])
     table = fasta.byte_codes(seqs)
-    if table is None or seqlen == 0:
+    if table is None:
         return None
     m = np.frombuffer("".join(seqs).translate(table).encode("latin-1"), dtype=np.uint8).reshape(len(seqs), seqlen)
     lines = []
@@ -264,6 +265,11 @@ def process_pipe(indexed_paths, args):
             raw = sys.stdin.buffer.read()
             if not raw.isascii():      # the reference reads TEXT (sys.stdin.readlines(), :231): what a byte >= 0x80 is, or whether
                 raise PfaError(PFA_ERR_UNSUPPORTED, "standard input holds bytes that are not ASCII")       # it kills the run, is the text layer's call
+            if b"\r" in raw.replace(b"\r\n", b""):
+                # a carriage return that is not part of \r\n: a line end in a FILE (open(file, 'r'): universal newlines, what the native
+                # parser implements), but not on standard input, which Python splits at \n only — there it is a character of its line
+                # (found by tools/g14_explore.py: a file with bare-CR line ends is one header line when piped)
+                raise PfaError(PFA_ERR_UNSUPPORTED, "standard input holds a bare carriage return")
             aln = fasta.parse_fasta_bytes(raw, 128)
             status = PFA_FILE_NOT_FASTA if aln is None else (0 if aln.same_length else PFA_FILE_UNEQUAL)
         except PfaError as e:
@@ -272,7 +278,7 @@ def process_pipe(indexed_paths, args):
             aln, status = None, PFA_FILE_UNSUPPORTED
             import io
             text = io.TextIOWrapper(io.BytesIO(raw), encoding=getattr(sys.stdin, "encoding", None) or "utf-8",
-                                    errors=getattr(sys.stdin, "errors", None) or "strict")   # sys.stdin.readlines(), :231
+                                    errors=getattr(sys.stdin, "errors", None) or "strict", newline="\n")   # sys.stdin.readlines(), :231: lines end at \n only
             keys = args.pops.split(",") if args.pops else []
             got = text_alignment_units(fasta.read_text_alignment(text), path, args, keys)
             if got is not None:      # non-ASCII characters in sequence lines: read as text, the way the reference reads it

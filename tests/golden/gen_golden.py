@@ -990,6 +990,29 @@ def g13():
             os.unlink(os.path.join(dm, victim))
         mruns[label] = {"args": ["-d", "{TMP}/more"] + extra, "removed": removed, "stdout": rel(p.stdout.decode()), "returncode": 0}
     out["more_texts"] = {"files_hex": {k: v.hex() for k, v in more.items()}, "runs": mruns}
+    # (e) carriage returns on standard input: a line end in a file (open(file, 'r'): universal newlines), but sys.stdin splits at
+    #     \n only — a piped file with bare-CR line ends is ONE header line (one sequence, no sites), \r\r\n ends a line like \r\n, and
+    #     a bare CR inside a sequence line is one of its characters (tools/g14_explore.py ran into the first)
+    cr = {
+        "bare_cr": b">a\rACGT\r>b\rACGA\r>c\rACGA\r",
+        "crlf": b">a\r\nACGT\r\n>b\r\nACGA\r\n>c\r\nACGA\r\n",
+        "cr_cr_lf": b">a\r\r\nACGT\r\r\n>b\r\r\nACGA\r\r\n>c\r\r\nAGGA\r\r\n",
+        "cr_inside_sequence": b">a\nAC\rGT\n>b\nAC\rGA\n>c\nACTGA\n",
+        "cr_inside_header": b">a\rx\nACGTAC\n>b\ry\nACGAAC\n>c\nACGAAT\n",
+    }
+    pruns = []
+    for label, blob in cr.items():
+        for extra in ([], ["--cds"], ["-n", "gene 1", "--jc"]):
+            p = ref_cli(["--pipe", "-s"] + extra, stdin_bytes=blob)
+            pruns.append({"label": label, "args": ["--pipe", "-s"] + extra, "returncode": p.returncode, "stdout": p.stdout.decode(),
+                          "stderr_tail": (p.stderr.decode().strip().splitlines() or [""])[-1] if p.returncode else None})
+        path = os.path.join(tmp, label + ".fa")
+        with open(path, "wb") as fh:
+            fh.write(blob)
+        p = ref_cli(["-f", path, "-s"])
+        pruns.append({"label": label, "args": ["-f", "{TMP}/" + label + ".fa", "-s"], "returncode": p.returncode, "stdout": rel(p.stdout.decode()),
+                      "stderr_tail": (p.stderr.decode().strip().splitlines() or [""])[-1] if p.returncode else None})
+    out["carriage_returns"] = {"texts_hex": {k: v.hex() for k, v in cr.items()}, "runs": pruns}
     shutil.rmtree(tmp)
     dump("g13_cli_odd_inputs.json", out)
 

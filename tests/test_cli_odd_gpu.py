@@ -240,3 +240,27 @@ def test_more_awkward_file_contents(gpu, g13, tmp_path, monkeypatch, mode):
         rc, out = run_inproc([a.replace("{TMP}", str(tmp_path)) for a in want["args"]])
         assert rc == 0
         same_lines(out, want["stdout"].replace("{TMP}", str(tmp_path)), "--cds" in want["args"], "--jc" in want["args"])
+
+
+def test_carriage_returns_on_standard_input_and_in_files(gpu, g13, tmp_path, monkeypatch):
+    """A carriage return ends a line in a FILE (open(file, 'r'): universal newlines) but not on standard input, which Python
+    splits at \\n only: a piped file with bare-CR line ends is one header line (one sequence, no sites), \\r\\r\\n ends a line like
+    \\r\\n, a bare CR inside a sequence line is one of its characters — the reference's `--pipe` and `-f` on the same five texts."""
+    import io
+    cr = g13["carriage_returns"]
+    for run in cr["runs"]:
+        blob = bytes.fromhex(cr["texts_hex"][run["label"]])
+        cds, jc = "--cds" in run["args"], "--jc" in run["args"]
+        if "--pipe" in run["args"]:
+            monkeypatch.setattr(sys, "stdin", io.TextIOWrapper(io.BytesIO(blob), encoding="utf-8", errors="surrogateescape", newline="\n"))
+            rc, out = run_inproc(run["args"])
+        else:
+            (tmp_path / f"{run['label']}.fa").write_bytes(blob)
+            rc, out = run_inproc([a.replace("{TMP}", str(tmp_path)) for a in run["args"]])
+        assert rc == run["returncode"] == 0, run
+        same_lines(out, run["stdout"].replace("{TMP}", str(tmp_path)), cds, jc)
+    # and through a real pipe
+    for run in cr["runs"]:
+        if run["label"] in ("bare_cr", "cr_inside_sequence") and run["args"] == ["--pipe", "-s"]:
+            p = run_proc(run["args"], stdin=bytes.fromhex(cr["texts_hex"][run["label"]]))
+            assert p.returncode == 0 and p.stdout.decode() == run["stdout"], (run["label"], p.stdout, p.stderr[-500:])

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Hunt for differences from the reference beyond the frozen G14 seeds.
-  make FIRST COUNT OUT.json   (build container: runs /root/reference/PolyFastA.py on synth.mixed_directory(seed) for COUNT seeds)
+  make FIRST COUNT OUT.json [extras]   (build container; `extras`: also -f lists, --pipe, and populations at function level; runs /root/reference/PolyFastA.py on synth.mixed_directory(seed) for COUNT seeds)
   check IN.json               (GPU box: python -m polyfasta_amd on the same directories, both ingest modes, every line)
 The JSON is scratch (not a fixture); a seed that shows a difference belongs into tests/golden/gen_golden.py's G14_SEEDS."""
+import contextlib
+import io
 import json
 import os
 import shutil
@@ -24,7 +26,13 @@ def write_dir(top, files):
     return d
 
 
-def make(first, count, out):
+def make(first, count, out, extras=False):
+    global ref
+    if extras:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("PolyFastA", "/root/reference/PolyFastA.py")
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
     cases = []
     for seed in range(first, first + count):
         files, flags = synth.mixed_directory(seed)
@@ -48,8 +56,57 @@ def make(first, count, out):
             os.unlink(os.path.join(d, victim))
             if len(removed) >= len(files):
                 break
+        case = {"seed": seed, "flags": flags, "runs": runs}
+        if extras:
+            for name in removed:      # the -d runs took them out; the extra runs see the whole directory again
+                with open(os.path.join(d, name), "wb") as fh:
+                    fh.write(files[name])
+            env = {**os.environ, "PYTHONHASHSEED": "0", "PYTHONUTF8": "1"}
+            names = sorted(files)
+            # -f with the files as a list, last first (the reference sorts the paths, PolyFastA.py:104)
+            p = subprocess.run([sys.executable, "/root/reference/PolyFastA.py", "-f"] + [os.path.join(d, n) for n in reversed(names)] + ["-s"] + flags,
+                               capture_output=True, env=env)
+            case["files_run"] = {"returncode": p.returncode, "stdout": p.stdout.decode().replace(top + "/", "{TMP}/"),
+                                 "stderr_tail": p.stderr.decode().strip().splitlines()[-1].replace(top + "/", "{TMP}/") if p.returncode else None}
+            # --pipe, the first three files one by one (-n on two of them)
+            case["pipe"] = []
+            for j, n in enumerate(names[:3]):
+                argv = ["--pipe", "-s"] + flags + (["-n", n] if j != 1 else [])
+                p = subprocess.run([sys.executable, "/root/reference/PolyFastA.py"] + argv, input=files[n], capture_output=True, env=env)
+                case["pipe"].append({"file": n, "argv": argv, "returncode": p.returncode, "stdout": p.stdout.decode(),
+                                     "stderr_tail": p.stderr.decode().strip().splitlines()[-1] if p.returncode else None})
+            # -p: the reference's own command line dies on every input under Python 3 (len() of a filter object, :126), so the
+            # lines come from its functions on the split it intends, file by file as main() would (:104-140)
+            keys = ["pop2", "nopop", "pop1", "s1_"]
+            cds, jc = "--cds" in flags, "--jc" in flags
+            buf, skipped = io.StringIO(), []
+            with contextlib.redirect_stdout(buf):
+                for n in names:
+                    try:
+                        dd = ref.readfasta(os.path.join(d, n), False)
+                    except UnicodeDecodeError:
+                        skipped.append(n)
+                        continue
+                    if type(dd) != dict:
+                        continue
+                    lens = [len(x) for x in dd.values()]
+                    if any(x != lens[0] for x in lens):
+                        print(f"# Sequences do not have the same length: {n}")
+                        continue
+                    if cds and lens[0] % 3:
+                        print(f"# CDS sequence length is not a multiple of 3: {n}")
+                    for pop in keys:
+                        grp = [k for k in dd if pop in k]
+                        if not grp:
+                            print(f"# Pop {pop} string was not found in fasta headers.")
+                            continue
+                        try:
+                            ref.print_result({k: dd[k] for k in grp}, lens[0], cds, "", "a", n, pop, True, 0, jc)
+                        except ZeroDivisionError:
+                            print(f"!ZeroDivisionError {n} {pop}")
+            case["pops"] = {"keys": keys, "skipped": skipped, "stdout": buf.getvalue().replace(top + "/", "{TMP}/")}
         shutil.rmtree(top)
-        cases.append({"seed": seed, "flags": flags, "runs": runs})
+        cases.append(case)
         if seed % 25 == 0:
             print(f"seed {seed}", flush=True)
     json.dump({"cases": cases}, open(out, "w"))
@@ -114,6 +171,74 @@ def check(path):
                 if diff:
                     bad += 1
                     print(f"DIFFERENCE seed {case['seed']} mode {mode} flags {flags} removed {run['removed']}: {diff}", flush=True)
+            # the extra runs (made with `extras`): the directory whole again
+            if "files_run" in case:
+                for name, blob in files.items():
+                    with open(os.path.join(d, name), "wb") as fh:
+                        fh.write(blob)
+                names = sorted(files)
+
+                def lines_differ(got, want, what):
+                    nonlocal bad, rows
+                    gl, wl = got.split("\n"), want.split("\n")
+                    if len(gl) != len(wl):
+                        bad += 1
+                        print(f"DIFFERENCE seed {case['seed']} mode {mode} {what}: {len(gl)} lines != {len(wl)}: {gl[-3:]} / {wl[-3:]}", flush=True)
+                        return
+                    for a, b in zip(gl, wl):
+                        if a != b and cds and not b.startswith(("#", "!")) and a.split(",")[0] == b.split(",")[0] and a.split(",")[1:3] != b.split(",")[1:3]:
+                            b = ",".join(b.split(",")[:1] + a.split(",")[1:3] + b.split(",")[3:])      # (ties: judged in the -d run above)
+                        if a != b and (b.startswith(("#", "!")) or "," not in b or C.row_matches(a, b, cds, jc) is not None):
+                            bad += 1
+                            print(f"DIFFERENCE seed {case['seed']} mode {mode} {what}: {a!r} != {b!r}", flush=True)
+                            return
+                        rows += bool(b) and not b.startswith("#")
+
+                fr = case["files_run"]
+                argv = ["-f"] + [os.path.join(d, n) for n in reversed(names)] + ["-s"] + flags
+                if fr["returncode"] == 0:
+                    rc, out = run_inproc(argv)
+                    lines_differ(out, fr["stdout"].replace("{TMP}", top), "-f list") if rc == 0 else print(f"DIFFERENCE seed {case['seed']} -f list: exit code {rc}")
+                    bad += rc != 0
+                else:
+                    p = run_proc(argv, env=env)
+                    tail = p.stderr.decode().strip().splitlines()[-1] if p.stderr.strip() else ""
+                    if p.returncode != fr["returncode"] or tail != fr["stderr_tail"].replace("{TMP}", top):
+                        bad += 1
+                        print(f"DIFFERENCE seed {case['seed']} mode {mode} -f list: exit {p.returncode} {tail!r} != {fr['returncode']} {fr['stderr_tail']!r}", flush=True)
+                    else:
+                        lines_differ(p.stdout.decode(), fr["stdout"].replace("{TMP}", top), "-f list (dies)")
+                for pr in case["pipe"] if mode == "direct" else []:      # (standard input does not go through the ingest)
+                    if pr["returncode"] == 0:
+                        keep = sys.stdin
+                        sys.stdin = io.TextIOWrapper(io.BytesIO(files[pr["file"]]), encoding="utf-8", errors="surrogateescape")
+                        try:
+                            rc, out = run_inproc(pr["argv"])
+                        except BaseException as e:      # noqa: BLE001
+                            rc, out = -1, f"{type(e).__name__}: {e}"
+                        finally:
+                            sys.stdin = keep
+                        if rc != 0:
+                            bad += 1
+                            print(f"DIFFERENCE seed {case['seed']} --pipe {pr['file']}: {rc} {out[-200:]!r}", flush=True)
+                        else:
+                            lines_differ(out, pr["stdout"], f"--pipe {pr['file']}")
+                        continue
+                    p = run_proc(pr["argv"], env=env, stdin=files[pr["file"]])
+                    tail = p.stderr.decode().strip().splitlines()[-1] if p.returncode else None
+                    if p.returncode != pr["returncode"] or tail != pr["stderr_tail"]:
+                        bad += 1
+                        print(f"DIFFERENCE seed {case['seed']} mode {mode} --pipe {pr['file']}: exit {p.returncode} {tail!r} != {pr['returncode']} {pr['stderr_tail']!r}", flush=True)
+                    else:
+                        lines_differ(p.stdout.decode(), pr["stdout"], f"--pipe {pr['file']}")
+                pp = case["pops"]
+                if not any(ln.startswith("!") for ln in pp["stdout"].split("\n")):
+                    for n in pp["skipped"]:
+                        os.unlink(os.path.join(d, n))
+                    rc, out = run_inproc(["-d", d, "-s", "-p", ",".join(pp["keys"])] + flags)
+                    # the reference's functions print no "is not FASTA" line here (readfasta's print went into the same capture): both have it
+                    lines_differ(out, pp["stdout"].replace("{TMP}", top), "-p") if rc == 0 else print(f"DIFFERENCE seed {case['seed']} -p: exit code {rc}")
+                    bad += rc != 0
             shutil.rmtree(top)
     for u in unfixed:
         print(f"tie the reference does not fix: seed {u[0]} {u[1]}: printed {u[2]}, the reference under PYTHONHASHSEED=0 {u[3]}; the checker's outcomes {u[4]}; printed the commonest: {u[5]}")
@@ -124,6 +249,6 @@ def check(path):
 
 if __name__ == "__main__":
     if sys.argv[1] == "make":
-        make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+        make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], extras=len(sys.argv) > 5 and sys.argv[5] == "extras")
     else:
         sys.exit(check(sys.argv[2]))
