@@ -1013,6 +1013,42 @@ def g13():
         pruns.append({"label": label, "args": ["-f", "{TMP}/" + label + ".fa", "-s"], "returncode": p.returncode, "stdout": rel(p.stdout.decode()),
                       "stderr_tail": (p.stderr.decode().strip().splitlines() or [""])[-1] if p.returncode else None})
     out["carriage_returns"] = {"texts_hex": {k: v.hex() for k, v in cr.items()}, "runs": pruns}
+    # (f) files in which no population key is found (tools/g14_explore.py ran into them): what the reference prints for them —
+    #     the comment lines of main() (:110-140), from its functions on the split it intends, as (c) — hangs on the text reader alone:
+    #     a length of 3 CHARACTERS that is 4 bytes, sequences equally long in bytes but not in characters (an upper-cased sharp s), blanks
+    #     and control white space at line ends that do not count as sites; and one file in which one key is found and one is not
+    nk = {
+        "three_characters_four_bytes.fa": b">s0\tdesc\nA\xc3\xa9A\n",
+        "equal_in_bytes_only.fa": b">s0\nC\xc7\x86AAGT\r>s1\nCT\xc7\x86AGG\r>s0\r\nCTAA\xc3\x9fT\r",
+        "blanks_at_line_ends.fa": b">s0,x=0\nG\t\r\nG \nC \nT\x1f\nT\n\nA\r\nC\x0c\n>s1,x=1\nG\t\r\nG \nC \nT\x1f\nT\n\nC\r\nC\n",
+        "one_key_of_two.fa": b">a_pop1\nACG \nTAC\t\n>b_pop1\nACG\nTAA\x1f\n>c_other\nACGTAA\n",
+    }
+    dn = os.path.join(tmp, "nokey")
+    os.makedirs(dn)
+    for fn, blob in nk.items():
+        with open(os.path.join(dn, fn), "wb") as fh:
+            fh.write(blob)
+    keys = ["pop2", "nopop", "pop1"]
+    nruns = []
+    for cds, jc in ((False, False), (True, False), (True, True)):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            for fn in sorted(nk):
+                dd = ref.readfasta(os.path.join(dn, fn), False)
+                lens = [len(x) for x in dd.values()]
+                if any(x != lens[0] for x in lens):
+                    print(f"# Sequences do not have the same length: {fn}")
+                    continue
+                if cds and lens[0] % 3:
+                    print(f"# CDS sequence length is not a multiple of 3: {fn}")
+                for pop in keys:
+                    grp = [k for k in dd if pop in k]
+                    if not grp:
+                        print(f"# Pop {pop} string was not found in fasta headers.")
+                        continue
+                    ref.print_result({k: dd[k] for k in grp}, lens[0], cds, "", "a", fn, pop, True, 0, jc)
+        nruns.append({"args": ["-d", "{TMP}/nokey", "-s", "-p", ",".join(keys)] + (["--cds"] if cds else []) + (["--jc"] if jc else []), "stdout": buf.getvalue()})
+    out["no_key_found"] = {"files_hex": {k: v.hex() for k, v in nk.items()}, "runs": nruns}
     shutil.rmtree(tmp)
     dump("g13_cli_odd_inputs.json", out)
 

@@ -264,3 +264,27 @@ def test_carriage_returns_on_standard_input_and_in_files(gpu, g13, tmp_path, mon
         if run["label"] in ("bare_cr", "cr_inside_sequence") and run["args"] == ["--pipe", "-s"]:
             p = run_proc(run["args"], stdin=bytes.fromhex(cr["texts_hex"][run["label"]]))
             assert p.returncode == 0 and p.stdout.decode() == run["stdout"], (run["label"], p.stdout, p.stderr[-500:])
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_files_in_which_no_population_key_is_found(gpu, g13, tmp_path, monkeypatch, mode):
+    """None of such a file's rows goes to the card, and it is the card's repack that tells exact row lengths and non-ASCII
+    characters: a length of 3 characters that is 4 bytes (no "not a multiple of 3" line), sequences equally long in bytes but not
+    in characters (unequal lengths), blanks and control white space at line ends that are no sites — the comment lines of the
+    reference's main() on its own reading of the files; and a file in which one key of two is found."""
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    nk = g13["no_key_found"]
+    d = tmp_path / "nokey"
+    d.mkdir()
+    for fn, hx in nk["files_hex"].items():
+        (d / fn).write_bytes(bytes.fromhex(hx))
+    for run in nk["runs"]:
+        rc, out = run_inproc([a.replace("{TMP}", str(tmp_path)) for a in run["args"]])
+        assert rc == 0
+        same_lines(out, run["stdout"], "--cds" in run["args"], "--jc" in run["args"])
+    # the same files one by one after -f
+    for run in nk["runs"]:
+        rc, out = run_inproc(["-f"] + [str(d / fn) for fn in sorted(nk["files_hex"], reverse=True)] + run["args"][2:])
+        assert rc == 0
+        same_lines(out, run["stdout"], "--cds" in run["args"], "--jc" in run["args"])

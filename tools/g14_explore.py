@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Hunt for differences from the reference beyond the frozen G14 seeds.
-  make FIRST COUNT OUT.json [extras]   (build container; `extras`: also -f lists, --pipe, and populations at function level; runs /root/reference/PolyFastA.py on synth.mixed_directory(seed) for COUNT seeds)
+  make FIRST COUNT OUT.json [extras] [wild]   (build container; `wild`: wild_directory below instead of synth.mixed_directory; `extras`: also -f lists, --pipe, and populations at function level; runs /root/reference/PolyFastA.py on synth.mixed_directory(seed) for COUNT seeds)
   check IN.json               (GPU box: python -m polyfasta_amd on the same directories, both ingest modes, every line)
 The JSON is scratch (not a fixture); a seed that shows a difference belongs into tests/golden/gen_golden.py's G14_SEEDS."""
 import contextlib
@@ -17,6 +17,86 @@ sys.path.insert(0, ROOT)
 from polyfasta_amd import synth  # noqa: E402
 
 
+WILD_FLAGS = ([], ["--cds"], ["--cds", "--jc"], ["--jc"])
+_PALETTES = ("ACGT", "ACGTacgt", "ACGTN-", "ACGTNRYKMSWBDHV-?*.", "ACGT \t", "ACGT\x0b\x0c\x1c\x1d\x1e\x1f", "ACGT>", "ACGT0123456789,;:|", "ACGTU", "ACGTéñßЖıǆ", "AC")
+_EOLS = ("\n", "\n", "\n", "\r\n", "\r", "\n\n", "\r\n\n", " \n", "\t\r\n", "\x0c\n", "\x1f\n")
+
+
+def wild_directory(seed):
+    """Directories further out than synth.mixed_directory: sites drawn from odd palettes (blanks and control white space INSIDE and
+    at the end of lines, `>` in sequences, digits and punctuation, U, characters whose upper case is longer than they are), line ends
+    mixed inside one file, lines before the first header, headers with leading blanks / commas / nothing at all, empty files,
+    files of blank lines, a header as the last line without a line end, one or two sequences, identical sequences, codons of N and
+    stops — and file names with blanks and commas.  (dict name -> bytes, flags)"""
+    import numpy as np
+    rng = np.random.default_rng([int(seed), 77])
+    flags = list(WILD_FLAGS[seed % len(WILD_FLAGS)])
+    files = {}
+    for i in range(int(rng.integers(3, 16))):
+        n = int(rng.choice([1, 2, 2, 3, 4, 5, 9, 20]))
+        L = int(rng.choice([0, 1, 2, 3, 4, 6, 9, 12, 30, 31, 63, 66, 128, 129, 300]))
+        pal = _PALETTES[int(rng.integers(0, len(_PALETTES)))]
+        odd = float(rng.choice([0.0, 0.0, 0.02, 0.2]))
+        base = [str(rng.choice(list("ACGT"))) for _ in range(L)]
+        seqs = []
+        for r in range(n):
+            x = list(base)
+            for j in rng.integers(0, max(L, 1), size=int(rng.integers(0, L // 10 + 2))).tolist():
+                if L:
+                    x[j] = str(rng.choice(list("ACGT")))
+            if odd and L:
+                for j in np.flatnonzero(rng.random(L) < odd).tolist():
+                    x[j] = str(rng.choice(list(pal)))
+            seqs.append("".join(x))
+        if rng.random() < 0.1 and n > 1:
+            seqs = [seqs[0]] * n
+        hk = int(rng.integers(0, 8))
+        heads = [(f"s{r}_pop{1 + r % 2}", f" s{r}", f"s{r},x={r}", f"s{r}\tdesc", "", f"s{r % 2}", f"s{r} pop1 ", f"ſ{r}é")[hk] for r in range(n)]
+        kind = int(rng.integers(0, 14))
+        eols = [str(rng.choice(list(_EOLS[:5]) if kind != 1 else list(_EOLS))) for _ in range(4 * n + 8)]
+        import itertools
+        e = itertools.cycle(eols)
+        wrap = int(rng.choice([0, 0, 0, 60, 7, 1]))
+        text = ""
+        if kind == 2:
+            text += "ACGT" + next(e) + "  stray line" + next(e)
+        for r, x in enumerate(seqs):
+            text += ">" + heads[r] + next(e)
+            if wrap and x:
+                for k in range(0, len(x), wrap):
+                    text += x[k:k + wrap] + next(e)
+            else:
+                text += x + next(e)
+            if kind == 3 and r == 0:
+                text += next(e) + "   " + next(e)
+        if kind == 4:
+            text = ""
+        elif kind == 5:
+            text = "\n\n\r\n \n"
+        elif kind == 6:
+            text += ">last header without a line end"
+        elif kind == 7:
+            text = text.rstrip("\r\n \t\x0c\x1f")
+        elif kind == 8 and n > 1 and L > 2:
+            text = text.replace(seqs[-1], seqs[-1][:-1], 1)
+        elif kind == 9:
+            text = " " + text
+        name = (f"w{i:02d}.fa", f"w{i:02d} x.fa", f"w{i:02d},y.fasta", f"w{i:02d}.é.fa")[int(rng.integers(0, 4))] if rng.random() < 0.3 else f"w{i:02d}.fa"
+        files[name] = text.encode("utf-8")
+    return files, flags
+
+
+GENERATORS = {"mixed": synth.mixed_directory, "wild": wild_directory}
+
+
+def norm(line, files):
+    """a row whose file name holds commas, with the commas of the name taken out (the rows are compared column by column)"""
+    for name in files:
+        if "," in name and line.startswith(name + ","):
+            return name.replace(",", ";") + line[len(name):]
+    return line
+
+
 def write_dir(top, files):
     d = os.path.join(top, "d")
     os.makedirs(d)
@@ -26,7 +106,7 @@ def write_dir(top, files):
     return d
 
 
-def make(first, count, out, extras=False):
+def make(first, count, out, extras=False, gen="mixed"):
     global ref
     if extras:
         import importlib.util
@@ -35,7 +115,7 @@ def make(first, count, out, extras=False):
         spec.loader.exec_module(ref)
     cases = []
     for seed in range(first, first + count):
-        files, flags = synth.mixed_directory(seed)
+        files, flags = GENERATORS[gen](seed)
         top = tempfile.mkdtemp()
         d = write_dir(top, files)
         runs, removed = [], []
@@ -51,7 +131,13 @@ def make(first, count, out, extras=False):
             names = sorted(os.listdir(d))
             seen = [ln.split(",")[0] if not ln.startswith("#") else ln.rsplit(": ", 1)[-1].rsplit(" ", 1)[-1] for ln in o.splitlines() if ln]
             seen = [x for x in seen if x in names]
-            victim = names[names.index(seen[-1]) + 1] if seen else names[0]
+            # the file it died on: the last one named in stdout (a comment line may precede the death) or the one after it —
+            # whichever kills the reference when it is the only input
+            k = names.index(seen[-1]) if seen else -1
+            cands = [names[j] for j in (k, k + 1) if 0 <= j < len(names)]
+            victim = next((c for c in cands if subprocess.run([sys.executable, "/root/reference/PolyFastA.py", "-f", os.path.join(d, c), "-s"] + flags,
+                                                              capture_output=True, env={**os.environ, "PYTHONHASHSEED": "0", "PYTHONUTF8": "1"}).returncode != 0), cands[-1])
+            run["victim"] = victim
             removed.append(victim)
             os.unlink(os.path.join(d, victim))
             if len(removed) >= len(files):
@@ -109,14 +195,15 @@ def make(first, count, out, extras=False):
         cases.append(case)
         if seed % 25 == 0:
             print(f"seed {seed}", flush=True)
-    json.dump({"cases": cases}, open(out, "w"))
+    json.dump({"generator": gen, "cases": cases}, open(out, "w"))
 
 
 def check(path):
     from tests import _cases as C
     from tests.test_cli_odd_gpu import MODES, run_inproc, run_proc
     from oracle import polyfasta_oracle as orc
-    cases = json.load(open(path))["cases"]
+    blob = json.load(open(path))
+    cases, generate = blob["cases"], GENERATORS[blob.get("generator", "mixed")]
     bad = rows = 0
     unfixed = []
     for mode, env in MODES.items():
@@ -124,7 +211,7 @@ def check(path):
             os.environ.pop(k, None)
         os.environ.update(env)
         for case in cases:
-            files, flags = synth.mixed_directory(case["seed"])
+            files, flags = generate(case["seed"])
             cds, jc = "--cds" in flags, "--jc" in flags
             top = tempfile.mkdtemp()
             d = write_dir(top, files)
@@ -144,7 +231,7 @@ def check(path):
                     p = run_proc(argv, env=env)
                     rc, out = p.returncode, p.stdout.decode()
                     tail = p.stderr.decode().strip().splitlines()[-1] if p.stderr.strip() else ""
-                gl, wl = out.split("\n"), want.split("\n")
+                gl, wl = [norm(x, files) for x in out.split("\n")], [norm(x, files) for x in want.split("\n")]
                 diff = None
                 if rc != run["returncode"]:
                     diff = f"exit code {rc} != {run['returncode']}"
@@ -158,7 +245,7 @@ def check(path):
                             # sites_S / sites_N differ: a tie on which the reference differs from itself (its digit follows its hash
                             # seed, G15)?  Then both pairs are outcomes of the checker's restatement of that freedom; the product is
                             # to print the commonest one, and the rest of the row must agree.
-                            dd = orc.readfasta(os.path.join(d, a.split(",")[0]))
+                            dd = orc.readfasta(os.path.join(d, a.split(",")[0].replace(";", ",")))
                             outs = orc.count_syn_outcomes(dd, len(next(iter(dd.values()))), trials=600, seed=1)
                             pa, pb = tuple(float(x) for x in a.split(",")[1:3]), tuple(float(x) for x in b.split(",")[1:3])
                             if pa in outs and pb in outs:
@@ -180,7 +267,7 @@ def check(path):
 
                 def lines_differ(got, want, what):
                     nonlocal bad, rows
-                    gl, wl = got.split("\n"), want.split("\n")
+                    gl, wl = [norm(x, files) for x in got.split("\n")], [norm(x, files) for x in want.split("\n")]
                     if len(gl) != len(wl):
                         bad += 1
                         print(f"DIFFERENCE seed {case['seed']} mode {mode} {what}: {len(gl)} lines != {len(wl)}: {gl[-3:]} / {wl[-3:]}", flush=True)
@@ -249,6 +336,6 @@ def check(path):
 
 if __name__ == "__main__":
     if sys.argv[1] == "make":
-        make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], extras=len(sys.argv) > 5 and sys.argv[5] == "extras")
+        make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], extras="extras" in sys.argv[5:], gen="wild" if "wild" in sys.argv[5:] else "mixed")
     else:
         sys.exit(check(sys.argv[2]))
