@@ -97,13 +97,18 @@ def readfasta(file, stdin):
     import sys
     raw = sys.stdin.buffer.read() if stdin else None
     try:
+        if stdin and b"\r" in raw.replace(b"\r\n", b""):
+            # standard input is split at \n only (a bare carriage return is a character of its line there, not a line end as in a
+            # file: cli.process_pipe)
+            raise PfaError(PFA_ERR_UNSUPPORTED, "standard input holds a bare carriage return")
         aln = fasta.parse_fasta_bytes(raw) if stdin else fasta.read_fasta_file(file)
         d = None if aln is None else aln.to_dict()
     except PfaError as e:       # non-ASCII characters in sequence lines: the reference's own text reading (a character is a site)
         if e.code != PFA_ERR_UNSUPPORTED:
             raise
         if stdin:
-            d = fasta.read_text_alignment(io.TextIOWrapper(io.BytesIO(raw), encoding=getattr(sys.stdin, "encoding", None) or "utf-8"))
+            d = fasta.read_text_alignment(io.TextIOWrapper(io.BytesIO(raw), encoding=getattr(sys.stdin, "encoding", None) or "utf-8",
+                                                           errors=getattr(sys.stdin, "errors", None) or "strict", newline="\n"))
         else:
             with open(file, "r") as fh:
                 d = fasta.read_text_alignment(fh)

@@ -89,6 +89,68 @@ def wild_directory(seed):
 GENERATORS = {"mixed": synth.mixed_directory, "wild": wild_directory}
 
 
+def _call(fn, *a):
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            return fn(*a)
+    except Exception as e:      # noqa: BLE001
+        return "!" + type(e).__name__
+
+
+def _sha(x):
+    import hashlib
+    return hashlib.sha1(repr(x).encode()).hexdigest()[:16]
+
+
+def api_record(mod, path):
+    """what the statistics functions of `mod` (the reference, or polyfasta_amd.api) return for one file, in a form that can be
+    compared: lists as they are when short, hashed when long; floats as floats; exceptions by name"""
+    d = _call(mod.readfasta, path, False)
+    if not isinstance(d, dict):
+        return {"readfasta": d}
+    rec = {"readfasta": _sha(list(d.items())), "n": len(d)}
+    lens = [len(x) for x in d.values()]
+    if not lens or any(x != lens[0] for x in lens):
+        return rec
+    L = lens[0]
+    got = _call(mod.getvarsites, d, L)
+    if isinstance(got, str):
+        rec["getvarsites"] = got
+        return rec
+    pos, var = got
+    rec["pos"] = _sha(list(pos))
+    rec["var"] = _sha([list(c) for c in var])
+    rec["S"] = len(var)
+    if len(var):
+        sfs = _call(mod.getsfs, var)
+        rec["getsfs"] = sfs if isinstance(sfs, str) else [int(x) for x in sfs]
+        for name in ("nucleotide_diversity", "wattersons_theta", "Dvar"):
+            rec[name] = _call(getattr(mod, name), var)
+        for jc in (False, True):
+            p = _call(mod.polymorphism, var, L, jc)
+            rec[f"polymorphism_jc{int(jc)}"] = p if isinstance(p, str) else list(p)
+    c = _call(mod.getvarCDSsites, d, L)
+    rec["getvarCDSsites"] = c if isinstance(c, str) else [c[0], sorted(int(x) for x in c[1]), sorted(int(x) for x in c[2]), c[3], c[4]]
+    return rec
+
+
+def api_differs(a, b):
+    """first key on which two api_records differ (floats to 1e-9 relative), or None"""
+    def same(x, y):
+        if isinstance(x, float) or isinstance(y, float):
+            try:
+                return abs(float(x) - float(y)) <= 1e-9 * max(1.0, abs(float(x)), abs(float(y)))
+            except (TypeError, ValueError):
+                return x == y
+        if isinstance(x, (list, tuple)) and isinstance(y, (list, tuple)):
+            return len(x) == len(y) and all(same(p, q) for p, q in zip(x, y))
+        return x == y
+    for k in sorted(set(a) | set(b)):
+        if k not in a or k not in b or not same(a[k], b[k]):
+            return k
+    return None
+
+
 def norm(line, files):
     """a row whose file name holds commas, with the commas of the name taken out (the rows are compared column by column)"""
     for name in files:
@@ -191,6 +253,8 @@ def make(first, count, out, extras=False, gen="mixed"):
                         except ZeroDivisionError:
                             print(f"!ZeroDivisionError {n} {pop}")
             case["pops"] = {"keys": keys, "skipped": skipped, "stdout": buf.getvalue().replace(top + "/", "{TMP}/")}
+            # the statistics functions one by one (what polyfasta_amd/api.py mirrors), on every file the reference can read
+            case["api"] = {n: api_record(ref, os.path.join(d, n)) for n in names if n not in skipped}
         shutil.rmtree(top)
         cases.append(case)
         if seed % 25 == 0:
@@ -204,7 +268,7 @@ def check(path):
     from oracle import polyfasta_oracle as orc
     blob = json.load(open(path))
     cases, generate = blob["cases"], GENERATORS[blob.get("generator", "mixed")]
-    bad = rows = 0
+    bad = rows = api_files = 0
     unfixed = []
     for mode, env in MODES.items():
         for k in ("PFA_INGEST_NO_DIRECT", "PFA_INGEST_SLOT_BYTES"):
@@ -318,6 +382,15 @@ def check(path):
                         print(f"DIFFERENCE seed {case['seed']} mode {mode} --pipe {pr['file']}: exit {p.returncode} {tail!r} != {pr['returncode']} {pr['stderr_tail']!r}", flush=True)
                     else:
                         lines_differ(p.stdout.decode(), pr["stdout"], f"--pipe {pr['file']}")
+                if "api" in case and mode == "direct":
+                    from polyfasta_amd import api as product_api
+                    for n, want_rec in case["api"].items():
+                        got_rec = json.loads(json.dumps(api_record(product_api, os.path.join(d, n))))
+                        k = api_differs(got_rec, want_rec)
+                        if k is not None:
+                            bad += 1
+                            print(f"DIFFERENCE seed {case['seed']} api {n} {k}: {got_rec.get(k)!r} != {want_rec.get(k)!r}", flush=True)
+                        api_files += 1
                 pp = case["pops"]
                 if not any(ln.startswith("!") for ln in pp["stdout"].split("\n")):
                     for n in pp["skipped"]:
@@ -330,7 +403,7 @@ def check(path):
     for u in unfixed:
         print(f"tie the reference does not fix: seed {u[0]} {u[1]}: printed {u[2]}, the reference under PYTHONHASHSEED=0 {u[3]}; the checker's outcomes {u[4]}; printed the commonest: {u[5]}")
     bad += sum(1 for u in unfixed if not u[5])
-    print(f"g14_explore: {len(cases)} directories in {len(MODES)} ingest modes, {rows} rows compared, {bad} differences, {len(unfixed)} rows (both modes counted) on a tie the reference itself does not fix")
+    print(f"g14_explore: {len(cases)} directories in {len(MODES)} ingest modes, {rows} rows compared, {bad} differences, {len(unfixed)} rows (both modes counted) on a tie the reference itself does not fix; {api_files} files through the statistics functions one by one")
     return 1 if bad else 0
 
 
