@@ -68,7 +68,7 @@ class IngestBatch:
         self.bad = _arr(self._bad_ptr, self.n_files, np.uint32)
         if syn is not None and self._plan:
             from .scan import resolve_syn_ties
-            self.sites_s = resolve_syn_ties(self._plan, syn, self.n_sites[self.unit_file])
+            self.sites_s = resolve_syn_ties(self._plan, syn, self.n_sites[self.unit_file], missing_cols=res["missing_cols"])
         return res, syn, sfs
 
     def sfs_offsets(self):

@@ -174,18 +174,20 @@ def codon_sets(plan_handle, unit: int, n_sites: int, d_bases=None) -> np.ndarray
     return out
 
 
-def resolve_syn_ties(plan_handle, syn_num, n_sites, d_bases=None, every=None):
+def resolve_syn_ties(plan_handle, syn_num, n_sites, d_bases=None, every=None, missing_cols=None):
     """Per unit NaN, or — for a unit whose synonymous-site count sits on a two-decimal rounding tie — that count as the
     reference itself accumulates it, column by column in floating point (PolyFastA.py:307), replayed from the unit's codon
     sets (stats.syn_sites_replay / syn_sites_most_likely).  A handful of units in a thousand; everything else prints the same digits either way.
     Call it while the matrices of the plan's run are still on the card.  `every`: bool per unit — replay these whatever
-    their bins say (the API mirror returns the reference's count_syn itself)."""
+    their bins say (the API mirror returns the reference's count_syn itself).  `missing_cols`: the records' count of codon columns
+    without a clean codon — with it, units whose non-synonymous site count is zero in exact arithmetic are replayed as well
+    (stats.syn_tie_candidates)."""
     from . import stats
     n_sites = np.asarray(n_sites)
     out = np.full(len(n_sites), np.nan, dtype=np.float64)
     if syn_num is None or len(out) == 0:
         return out
-    tie = stats.syn_tie_candidates(syn_num, n_sites)
+    tie = stats.syn_tie_candidates(syn_num, n_sites, missing_cols)
     pick = tie if every is None else tie | np.asarray(every, dtype=bool)
     for i in np.flatnonzero(pick).tolist():
         sets = codon_sets(plan_handle, i, int(n_sites[i]), d_bases)
@@ -356,7 +358,7 @@ def scan_batch(batch: Batch, want_pos: bool = False, want_sn: bool = False, vari
             if out.syn_num is not None:
                 coding = (table.descs["flags"] & PFA_FLAG_CDS) != 0
                 out.sites_s = resolve_syn_ties(plan.handle, np.where(coding[:, None], out.syn_num, 0), table.descs["n_sites"],
-                                               every=coding if exact_syn else None)
+                                               every=coding if exact_syn else None, missing_cols=out.results["missing_cols"])
             return out
         finally:
             plan.close()

@@ -121,9 +121,13 @@ def _syn_float_by_codon():
 _SYN_FLOAT = None
 
 
-def syn_tie_candidates(syn_num, n_sites):
+def syn_tie_candidates(syn_num, n_sites, missing_cols=None):
     """Units whose synonymous-site count (or its complement, :167) sits on a two-decimal rounding boundary as far as double
-    precision can tell: bool[n_units].  `syn_num`: uint32[n_units, 65]; `n_sites`: alignment length per unit.  The
+    precision can tell — or whose complement, the non-synonymous site count (seqlen - missing) - count_syn (:167), is ZERO in
+    exact arithmetic (`missing_cols`: codon columns without a clean codon, per unit): the reference then divides by the
+    rounding noise of its own accumulation (pi_N = 1.5e16, a negative zero, or ZeroDivisionError when the noise is nil), so
+    those few units want the same last bits too (found by tools/g14_explore.py: `CTG>` / `AGGA` / `CCGT`, one clean column
+    worth 1.0 of 1 site).  bool[n_units].  `syn_num`: uint32[n_units, 65]; `n_sites`: alignment length per unit.  The
     reference's accumulated rounding error is below (columns) x ulp(sum); anything within a generous multiple of that of
     xxx.xx5 is replayed.  Units whose columns all hold at most 7 distinct codons are at least 1 / (200 x 1260) = 4e-6 away
     from any boundary (the sum is a multiple of 1/1260) and are not even looked at in floating point — unless they are so
@@ -134,6 +138,11 @@ def syn_tie_candidates(syn_num, n_sites):
     cols = n_sites / 3.0 + 1.0
     look = syn[:, 8:].any(axis=1) | (cols * np.spacing(np.maximum(n_sites, 1.0)) > 1e-8)
     out = np.zeros(len(syn), dtype=bool)
+    if missing_cols is not None and len(syn):
+        k3_all = 3.0 * np.arange(1, 65, dtype=np.float64)
+        x_all = (syn[:, 1:].astype(np.float64) / k3_all).sum(axis=1)
+        left = (n_sites - 3.0 * np.asarray(missing_cols, dtype=np.float64)) - x_all
+        out |= (np.abs(left) < 1e-6) & (x_all > 0)
     if not look.any():
         return out
     idx = np.flatnonzero(look)
@@ -142,7 +151,7 @@ def syn_tie_candidates(syn_num, n_sites):
     x = (bins[:, 1:] / k3).sum(axis=1)
     y = 100.0 * x
     d = np.abs(y - np.floor(y) - 0.5)
-    out[idx] = d < 1e-6 + 400.0 * cols[idx] * np.spacing(np.maximum(x, 1.0))
+    out[idx] |= d < 1e-6 + 400.0 * cols[idx] * np.spacing(np.maximum(x, 1.0))
     return out
 
 
@@ -261,11 +270,11 @@ def syn_sites_most_likely(sets, n_sites, draws=512):
     vals, counts = np.unique(totals, return_counts=True)
     by_pair = {}
     for v, c in zip(vals.tolist(), counts.tolist()):
-        pair = (round(v, 2), round(A - v, 2))
-        e = by_pair.setdefault(pair, [0, 0, v])
+        pair = (round(v, 2), round(A - v, 2), A - v == 0)      # (a non-synonymous site count of exactly zero is an outcome of its
+        e = by_pair.setdefault(pair, [0, 0, v])                 #  own: the reference then dies where it otherwise divides by noise)
         e[0] += c
         if c > e[1]:
             e[1], e[2] = c, v
-    base_pair = (round(base, 2), round(A - base, 2))
+    base_pair = (round(base, 2), round(A - base, 2), A - base == 0)
     best = max(by_pair.items(), key=lambda kv: (kv[1][0], kv[0] == base_pair, -kv[0][0]))
     return base if best[0] == base_pair else float(best[1][2])

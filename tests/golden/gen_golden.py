@@ -1155,9 +1155,24 @@ def g15():
         if len(seen) < 2 or cnt < 36:
             continue
         cases.append({"label": label, "text": text, "printed": [[a, b, c] for (a, b), c in sorted(seen.items())], "most_often": list(top)})
+    # One more kind (tools/g14_explore.py, wild directory 2181): four sites, one clean codon column of three codons worth 1.0
+    # synonymous site of 1 — the non-synonymous site count is zero in exact arithmetic, and the reference divides by it: by exactly
+    # 0.0 in the orders that sum to 1.0 (ZeroDivisionError, exit code 1), by 1.1e-16 in the others (a row with pi_N = 1.5e16).
+    text = ">s0,x=0\nCTG>\n\r   \n>s1,x=1\nAGGA\n>s2,x=2\nCCGT\r\n"
+    path = os.path.join(tmp, "x.fa")
+    with open(path, "w", newline="") as fh:
+        fh.write(text)
+    seen = Counter()
+    for hs in range(60):
+        p = subprocess.run([sys.executable, os.path.join(REF_DIR, "PolyFastA.py"), "-f", path, "-s", "--cds"], capture_output=True,
+                           env={**os.environ, "PYTHONHASHSEED": str(hs), "PYTHONUTF8": "1"})
+        seen[(p.returncode, p.stdout.decode(), p.stderr.decode().strip().splitlines()[-1] if p.returncode else "")] += 1
+    print(f"  G15 zero non-synonymous sites: {[(k[0], v) for k, v in seen.items()]}", flush=True)
+    zero = {"text": text, "outcomes": [{"returncode": k[0], "stdout": k[1], "stderr_tail": k[2], "runs": v} for k, v in sorted(seen.items())]}
+    assert len(seen) == 2 and max(seen.values()) >= 36
     shutil.rmtree(tmp)
     assert len(cases) >= 5 and cases[0]["label"].startswith("mixed_directory")
-    dump("g15_hash_seed_ties.json", {"hash_seeds": 60, "cases": cases})
+    dump("g15_hash_seed_ties.json", {"hash_seeds": 60, "cases": cases, "zero_nonsynonymous_sites": zero})
 
 
 if __name__ == "__main__":

@@ -196,3 +196,28 @@ def test_ties_the_reference_does_not_fix_print_what_it_prints_most_often_g15():
         if k["count_syn_order_free"]:
             sets = C.codon_sets_numpy(sub)
             assert stats.syn_sites_most_likely(sets, g["L"]) == stats.syn_sites_replay(sets)
+
+
+def test_zero_nonsynonymous_sites_die_or_print_like_the_reference_mostly_does_g15():
+    """Four sites, one clean codon column of three codons worth 1.0 synonymous site of 1: the non-synonymous site count is zero
+    in exact arithmetic, the reference divides by it — by 0.0 in most summation orders (ZeroDivisionError), by 1.1e-16 in the
+    others (pi_N = 1.5e16).  The unit is a candidate although it is no rounding tie, and the replay gives the commoner outcome."""
+    import io
+    from oracle import polyfasta_oracle as orc
+    z = C.load("g15_hash_seed_ties.json")["zero_nonsynonymous_sites"]
+    d = orc.parse_fasta_lines(io.StringIO(z["text"], newline=None))
+    m = fasta.matrix_from_dict(d)
+    L = m.shape[1]
+    sets = C.codon_sets_numpy(m)
+    missing = int((sets == 0).sum())
+    assert stats.syn_tie_candidates(C.syn_bins_numpy(m)[None, :], [L], [missing])[0]
+    assert not stats.syn_tie_candidates(C.syn_bins_numpy(m)[None, :], [L])[0]          # (no two-decimal tie)
+    x = stats.syn_sites_most_likely(sets, L)
+    most = max(z["outcomes"], key=lambda o: o["runs"])
+    assert most["returncode"] == 1 and most["stderr_tail"].startswith("ZeroDivisionError") and most["runs"] >= 36
+    assert (L - 3 * missing) - x == 0.0          # the commoner outcome: a division by exactly zero
+    # ordinary units are no candidates on this count
+    p = synth.make_params(50, 0.01)
+    for a in range(20):
+        mm = synth.synth_alignment(7, a, 300, p, coding=True)
+        assert not stats.syn_tie_candidates(C.syn_bins_numpy(mm)[None, :], [300], [int((C.codon_sets_numpy(mm) == 0).sum())])[0]

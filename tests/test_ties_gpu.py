@@ -228,3 +228,19 @@ def test_ties_the_reference_does_not_fix_g15(gpu, tmp_path, monkeypatch):
         dd = orc.parse_fasta_lines(io.StringIO(case["text"], newline=None))      # the reference's reader: dict header -> sequence
         L = len(next(iter(dd.values())))
         assert str(round(api.getvarCDSsites(dd, L)[0], 2)) == case["most_often"][0]
+
+
+def test_zero_nonsynonymous_sites_g15(gpu, tmp_path):
+    """G15 `zero_nonsynonymous_sites`: the reference dies with ZeroDivisionError in 41 of 60 runs and prints pi_N = 1.5e16 in
+    the others (its hash seed); the product does what it mostly does — the comment line, then the same death, exit code 1."""
+    import subprocess
+    import sys
+    z = C.load("g15_hash_seed_ties.json")["zero_nonsynonymous_sites"]
+    most = max(z["outcomes"], key=lambda o: o["runs"])
+    f = tmp_path / "x.fa"
+    f.write_bytes(z["text"].encode())
+    p = subprocess.run([sys.executable, "-m", "polyfasta_amd", "-f", str(f), "-s", "--cds"], capture_output=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    assert p.returncode == most["returncode"] == 1
+    assert p.stdout.decode() == most["stdout"]
+    assert p.stderr.decode().strip().splitlines()[-1] == most["stderr_tail"]

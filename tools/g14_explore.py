@@ -216,6 +216,14 @@ def make(first, count, out, extras=False, gen="mixed"):
                                capture_output=True, env=env)
             case["files_run"] = {"returncode": p.returncode, "stdout": p.stdout.decode().replace(top + "/", "{TMP}/"),
                                  "stderr_tail": p.stderr.decode().strip().splitlines()[-1].replace(top + "/", "{TMP}/") if p.returncode else None}
+            # the header line (no -s), and --out with its progress chatter (only where the reference gets through the directory)
+            if runs[-1]["returncode"] == 0 and not runs[-1]["removed"]:
+                p = subprocess.run([sys.executable, "/root/reference/PolyFastA.py", "-d", d] + flags, capture_output=True, env=env)
+                case["loud"] = {"returncode": p.returncode, "stdout": p.stdout.decode().replace(top + "/", "{TMP}/")}
+                outp = os.path.join(top, "out file.csv")
+                p = subprocess.run([sys.executable, "/root/reference/PolyFastA.py", "-d", d, "-o", outp] + flags, capture_output=True, env=env)
+                case["out"] = {"returncode": p.returncode, "stdout": p.stdout.decode().replace(top + "/", "{TMP}/"),
+                               "file": open(outp, encoding="utf-8", errors="surrogateescape").read().replace(top + "/", "{TMP}/") if os.path.exists(outp) else None}
             # --pipe, the first three files one by one (-n on two of them)
             case["pipe"] = []
             for j, n in enumerate(names[:3]):
@@ -264,7 +272,14 @@ def make(first, count, out, extras=False, gen="mixed"):
 
 def check(path):
     from tests import _cases as C
-    from tests.test_cli_odd_gpu import MODES, run_inproc, run_proc
+    from tests.test_cli_odd_gpu import MODES, run_proc
+    from tests.test_cli_odd_gpu import run_inproc as run_inproc_raw
+
+    def run_inproc(argv):      # an exception the reference did not raise is a difference, not the end of the check
+        try:
+            return run_inproc_raw(argv)
+        except BaseException as e:      # noqa: BLE001
+            return -1, f"{type(e).__name__}: {e}"
     from oracle import polyfasta_oracle as orc
     blob = json.load(open(path))
     cases, generate = blob["cases"], GENERATORS[blob.get("generator", "mixed")]
@@ -382,6 +397,18 @@ def check(path):
                         print(f"DIFFERENCE seed {case['seed']} mode {mode} --pipe {pr['file']}: exit {p.returncode} {tail!r} != {pr['returncode']} {pr['stderr_tail']!r}", flush=True)
                     else:
                         lines_differ(p.stdout.decode(), pr["stdout"], f"--pipe {pr['file']}")
+                if "loud" in case:
+                    rc, out = run_inproc(["-d", d] + flags)
+                    lines_differ(out, case["loud"]["stdout"].replace("{TMP}", top), "no -s") if rc == case["loud"]["returncode"] == 0 else print(f"DIFFERENCE seed {case['seed']} no -s: exit {rc}")
+                    outp = os.path.join(top, "out file.csv")
+                    rc, out = run_inproc(["-d", d, "-o", outp] + flags)
+                    want_o = case["out"]
+                    if rc != want_o["returncode"] or out != want_o["stdout"].replace("{TMP}", top):
+                        bad += 1
+                        print(f"DIFFERENCE seed {case['seed']} mode {mode} --out stdout: {out[-160:]!r} != {want_o['stdout'][-160:]!r}", flush=True)
+                    else:
+                        lines_differ(open(outp, encoding="utf-8", errors="surrogateescape").read(), want_o["file"].replace("{TMP}", top), "--out file")
+                    os.unlink(outp)
                 if "api" in case and mode == "direct":
                     from polyfasta_amd import api as product_api
                     for n, want_rec in case["api"].items():
