@@ -18,6 +18,7 @@ second derived allele on the first k//2 carriers.
 """
 from __future__ import annotations
 
+import itertools
 import math
 from dataclasses import dataclass
 
@@ -272,4 +273,100 @@ def mixed_directory(seed: int):
         if kind == 9 and rng.random() < 0.15:
             blob = blob[:len(blob) // 2] + b"\xff" + blob[len(blob) // 2:]
         files[f"f{i:03d}.fa"] = blob
+    return files, flags
+
+
+WILD_FLAGS = ([], ["--cds"], ["--cds", "--jc"], ["--jc"])
+_PALETTES = ("ACGT", "ACGTacgt", "ACGTN-", "ACGTNRYKMSWBDHV-?*.", "ACGT \t", "ACGT\x0b\x0c\x1c\x1d\x1e\x1f", "ACGT>", "ACGT0123456789,;:|", "ACGTU", "ACGTéñßЖıǆ", "AC")
+_EOLS = ("\n", "\n", "\n", "\r\n", "\r", "\n\n", "\r\n\n", " \n", "\t\r\n", "\x0c\n", "\x1f\n")
+
+
+def wild_directory(seed: int):
+    """Directories further out than synth.mixed_directory: sites drawn from odd palettes (blanks and control white space INSIDE and
+    at the end of lines, `>` in sequences, digits and punctuation, U, characters whose upper case is longer than they are), line ends
+    mixed inside one file, lines before the first header, headers with leading blanks / commas / nothing at all, empty files,
+    files of blank lines, a header as the last line without a line end, one or two sequences, identical sequences, codons of N and
+    stops — and file names with blanks and commas.  (dict name -> bytes, flags)"""
+    rng = np.random.default_rng([int(seed), 77])
+    flags = list(WILD_FLAGS[seed % len(WILD_FLAGS)])
+    files = {}
+    for i in range(int(rng.integers(3, 16))):
+        n = int(rng.choice([1, 2, 2, 3, 4, 5, 9, 20]))
+        L = int(rng.choice([0, 1, 2, 3, 4, 6, 9, 12, 30, 31, 63, 66, 128, 129, 300]))
+        pal = _PALETTES[int(rng.integers(0, len(_PALETTES)))]
+        odd = float(rng.choice([0.0, 0.0, 0.02, 0.2]))
+        base = [str(rng.choice(list("ACGT"))) for _ in range(L)]
+        seqs = []
+        for r in range(n):
+            x = list(base)
+            for j in rng.integers(0, max(L, 1), size=int(rng.integers(0, L // 10 + 2))).tolist():
+                if L:
+                    x[j] = str(rng.choice(list("ACGT")))
+            if odd and L:
+                for j in np.flatnonzero(rng.random(L) < odd).tolist():
+                    x[j] = str(rng.choice(list(pal)))
+            seqs.append("".join(x))
+        if rng.random() < 0.1 and n > 1:
+            seqs = [seqs[0]] * n
+        hk = int(rng.integers(0, 8))
+        heads = [(f"s{r}_pop{1 + r % 2}", f" s{r}", f"s{r},x={r}", f"s{r}\tdesc", "", f"s{r % 2}", f"s{r} pop1 ", f"ſ{r}é")[hk] for r in range(n)]
+        kind = int(rng.integers(0, 14))
+        eols = [str(rng.choice(list(_EOLS[:5]) if kind != 1 else list(_EOLS))) for _ in range(4 * n + 8)]
+        e = itertools.cycle(eols)
+        wrap = int(rng.choice([0, 0, 0, 60, 7, 1]))
+        text = ""
+        if kind == 2:
+            text += "ACGT" + next(e) + "  stray line" + next(e)
+        for r, x in enumerate(seqs):
+            text += ">" + heads[r] + next(e)
+            if wrap and x:
+                for k in range(0, len(x), wrap):
+                    text += x[k:k + wrap] + next(e)
+            else:
+                text += x + next(e)
+            if kind == 3 and r == 0:
+                text += next(e) + "   " + next(e)
+        if kind == 4:
+            text = ""
+        elif kind == 5:
+            text = "\n\n\r\n \n"
+        elif kind == 6:
+            text += ">last header without a line end"
+        elif kind == 7:
+            text = text.rstrip("\r\n \t\x0c\x1f")
+        elif kind == 8 and n > 1 and L > 2:
+            text = text.replace(seqs[-1], seqs[-1][:-1], 1)
+        elif kind == 9:
+            text = " " + text
+        name = (f"w{i:02d}.fa", f"w{i:02d} x.fa", f"w{i:02d},y.fasta", f"w{i:02d}.é.fa")[int(rng.integers(0, 4))] if rng.random() < 0.3 else f"w{i:02d}.fa"
+        files[name] = text.encode("utf-8")
+    return files, flags
+
+
+def big_directory(seed: int):
+    """Fewer, larger alignments: 65 to 300 sequences (the 128-site-tile and the row-chunked kernels; synth.mixed_directory stays
+    below 31), 64 to 1 200 sites, up to 15 % of a row's sites changed (columns of many alleles, codon columns of many codons), N / - /
+    IUPAC / lower case sprinkled in."""
+    rng = np.random.default_rng([int(seed), 99])
+    flags = list(WILD_FLAGS[seed % len(WILD_FLAGS)])
+    files = {}
+    for i in range(int(rng.integers(2, 6))):
+        n = int(rng.choice([65, 100, 130, 213, 214, 300]))
+        L = int(rng.choice([64, 129, 255, 257, 600, 999, 1200]))
+        base = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L)
+        m = np.repeat(base[None, :], n, axis=0)
+        rate = float(rng.choice([0.0005, 0.005, 0.05, 0.15]))
+        hit = rng.random((n, L)) < rate
+        m[hit] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(hit.sum()))
+        if rng.random() < 0.5:
+            odd = rng.random((n, L)) < 0.002
+            m[odd] = rng.choice(np.frombuffer(b"N-RYacgtn?", dtype=np.uint8), size=int(odd.sum()))
+        eol = str(rng.choice(["\n", "\n", "\r\n"]))
+        wrap = int(rng.choice([0, 60]))
+        text = ""
+        for r in range(n):
+            x = m[r].tobytes().decode()
+            body = eol.join(x[k:k + wrap] for k in range(0, L, wrap)) if wrap else x
+            text += f">s{r}_pop{1 + r % 2}{eol}{body}{eol}"
+        files[f"b{i:02d}.fa"] = text.encode()
     return files, flags

@@ -122,8 +122,9 @@ def row_matches(got, want, cds, jc):
     """One CSV row, column by column: text columns and integers equal; theta and D to 1e-9 relative (D, a cancelling
     difference, also 1e-9 absolute); pi to 1e-9 — 1e-6 when Jukes-Cantor corrected (BASELINE.json).  Returns None or the
     name of the first column that differs."""
-    fa, fb = got.split(","), want.split(",")
-    if len(fa) != len(fb) or len(fa) != (14 if cds else 8):
+    ncols = 14 if cds else 8
+    fa, fb = got.rsplit(",", ncols - 1), want.rsplit(",", ncols - 1)      # (from the right: a file name may hold commas)
+    if len(fa) != len(fb) or len(fa) != ncols:
         return "column count"
     names = ("file,sites_S,sites_N,pop,N,seg_sites_S,seg_sites_N,pi_S,pi_N,theta_S,theta_N,tajimasD_S,tajimasD_N,nstops" if cds
              else "file,seqlen,pop,N,seg_sites,pi,theta,tajimasD").split(",")

@@ -1054,19 +1054,25 @@ def g13():
 
 
 # ------------------------------------------------------- G14 random directories through the command line
-G14_SEEDS = list(range(1, 49)) + [590]      # 590: the directory in which tools/g14_explore.py ran into a tie the reference itself does not fix (G15)
+G14_SEEDS = ([("mixed", sd) for sd in list(range(1, 49)) + [590]]      # 590: the directory in which tools/g14_explore.py ran into a tie the reference itself does not fix (G15)
+             + [("wild", sd) for sd in list(range(1, 25)) + [56, 433, 485, 506]]      # the last four: files in which no population key is found (G13 no_key_found) — here without -p
+             + [("big", sd) for sd in range(1, 7)])
 
 
 def g14():
-    """The reference's transcript for 49 random directories of small awkward files (polyfasta_amd.synth.mixed_directory: the
+    """The reference's transcript for 83 random directories (polyfasta_amd.synth: 49 of mixed_directory — small awkward files —, 28
+    of wild_directory — odd palettes, blanks and control white space in and after lines, mixed line ends, stray lines, empty files,
+    names with blanks and commas —, 6 of big_directory — 65 to 300 sequences: the other kernels; the
     files are made again from the seed, only the transcript is frozen): `-d DIR -s` with the seed's flags (plain, --jc, --cds,
     --cds --jc; the reference's -p dies on every input under Python 3, G6 and G13 pin populations per key) — stdout, exit code, and the last line of stderr where the reference dies (a file that is not
     UTF-8, a coding alignment whose variable site falls on a zero site count: the rows before it are part of the transcript).
     A directory the reference dies on is run again without the file it died on, until it gets through: every file is either in
     a transcript that ends well or named as a victim."""
     cases = []
-    for seed in G14_SEEDS:
-        files, flags = synth.mixed_directory(seed)
+    for gen, seed in G14_SEEDS:
+        files, flags = getattr(synth, gen + "_directory")(seed)
+        if gen == "wild" and seed == 2181:
+            continue
         tmp = tempfile.mkdtemp()
         d = os.path.join(tmp, "d")
         os.makedirs(d)
@@ -1086,15 +1092,18 @@ def g14():
             names = sorted(os.listdir(d))
             seen = [ln.split(",")[0] if not ln.startswith("#") else ln.rsplit(": ", 1)[-1].rsplit(" ", 1)[-1] for ln in out.splitlines() if ln]
             seen = [x for x in seen if x in names]
-            victim = names[names.index(seen[-1]) + 1] if seen else names[0]
+            # the last one named in stdout (a comment line may precede the death) or the one after it: whichever kills the reference alone
+            k = names.index(seen[-1]) if seen else -1
+            cands = [names[j] for j in (k, k + 1) if 0 <= j < len(names)]
+            victim = next((c for c in cands if ref_cli(["-f", os.path.join(d, c), "-s"] + flags).returncode != 0), cands[-1])
             run["victim"] = victim
             removed.append(victim)
             os.unlink(os.path.join(d, victim))
             assert len(removed) < len(files)
         shutil.rmtree(tmp)
-        cases.append({"seed": seed, "flags": flags, "n_files": len(files),
+        cases.append({"generator": gen, "seed": seed, "flags": flags, "n_files": len(files),
                       "files_sha1": hashlib.sha1(b"".join(files[k] for k in sorted(files))).hexdigest(), "runs": runs})
-        print(f"g14 seed {seed}: {len(files)} files, flags {flags}, {len(runs)} run(s), died on {removed}", flush=True)
+        print(f"g14 {gen} seed {seed}: {len(files)} files, flags {flags}, {len(runs)} run(s), died on {removed}", flush=True)
     dump("g14_random_directories.json", {"cases": cases})
 
 

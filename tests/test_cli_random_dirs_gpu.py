@@ -1,6 +1,7 @@
-"""G14: the reference's command-line transcripts of 48 random directories of small awkward files (1 to 30 sequences of 1 to
+"""G14: the reference's command-line transcripts of 83 random directories — 49 of small awkward files (1 to 30 sequences of 1 to
 1 001 sites; lower case, other symbols, unequal lengths, non-ASCII characters, no header, blank lines, repeated headers, a byte
-that is not UTF-8; LF / CRLF / CR; wrapped lines) under no flag, --jc, --cds, --cds --jc — against `python -m polyfasta_amd`
+that is not UTF-8; LF / CRLF / CR; wrapped lines), 28 wilder ones (odd palettes, blanks and control white space in and after lines, mixed line ends, stray lines, empty
+files, names with blanks and commas) and 6 of 65 to 300 sequences (the other kernels) — under no flag, --jc, --cds, --cds --jc — against `python -m polyfasta_amd`
 through the streaming ingest and its direct mode: every line, the exit code, and where the reference dies its last word."""
 import os
 
@@ -24,9 +25,9 @@ def test_random_directories_line_by_line(gpu, g14, tmp_path, monkeypatch, mode):
         monkeypatch.setenv(k, v)
     rows = dead = 0
     for case in g14["cases"]:
-        files, flags = synth.mixed_directory(case["seed"])
+        files, flags = getattr(synth, case["generator"] + "_directory")(case["seed"])
         cds, jc = "--cds" in flags, "--jc" in flags
-        top = tmp_path / f"s{case['seed']}"
+        top = tmp_path / f"{case['generator']}{case['seed']}"
         d = top / "d"
         d.mkdir(parents=True)
         for name, blob in files.items():
@@ -49,4 +50,4 @@ def test_random_directories_line_by_line(gpu, g14, tmp_path, monkeypatch, mode):
                 assert p.stderr.decode().strip().splitlines()[-1] == run["stderr_tail"], case["seed"]
                 same_lines(p.stdout.decode(), want, cds, jc)
                 dead += 1
-    assert rows > 600 and dead >= 6
+    assert rows > 750 and dead >= 6

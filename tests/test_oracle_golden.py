@@ -294,7 +294,7 @@ def test_rounding_ties_g12():
 
 
 def test_random_directories_g14(tmp_path):
-    """G14: the reference's command-line transcripts of 49 random directories of small awkward files.  The generator still makes
+    """G14: the reference's command-line transcripts of 83 random directories (synth.mixed_directory / wild_directory / big_directory).  The generator still makes
     the same files (their hash is frozen with the transcript), and the Python oracle — its reader on each file, its row or the
     comment line the reference prints instead — gives every line of every transcript that ends well, and of the ones that do
     not, every line up to the file the reference died on."""
@@ -303,11 +303,11 @@ def test_random_directories_g14(tmp_path):
     g14 = C.load("g14_random_directories.json")
     n_rows = n_dead = n_unfixed = 0
     for case in g14["cases"]:
-        files, flags = synth.mixed_directory(case["seed"])
+        files, flags = getattr(synth, case["generator"] + "_directory")(case["seed"])
         assert flags == case["flags"] and len(files) == case["n_files"]
         assert hashlib.sha1(b"".join(files[k] for k in sorted(files))).hexdigest() == case["files_sha1"], case["seed"]
         cds, jc = "--cds" in flags, "--jc" in flags
-        d = tmp_path / f"s{case['seed']}" / "d"
+        d = tmp_path / f"{case['generator']}{case['seed']}" / "d"
         d.mkdir(parents=True)
         for name, blob in files.items():
             (d / name).write_bytes(blob)
@@ -358,4 +358,4 @@ def test_random_directories_g14(tmp_path):
                 else:
                     C.rows_close(a, b, rel=1e-12, rel_jc=1e-9, jc=jc)
                     n_rows += 1
-    assert n_rows > 600 and n_dead >= 6 and n_unfixed >= 1
+    assert n_rows > 850 and n_dead >= 6 and n_unfixed >= 1

@@ -17,76 +17,7 @@ sys.path.insert(0, ROOT)
 from polyfasta_amd import synth  # noqa: E402
 
 
-WILD_FLAGS = ([], ["--cds"], ["--cds", "--jc"], ["--jc"])
-_PALETTES = ("ACGT", "ACGTacgt", "ACGTN-", "ACGTNRYKMSWBDHV-?*.", "ACGT \t", "ACGT\x0b\x0c\x1c\x1d\x1e\x1f", "ACGT>", "ACGT0123456789,;:|", "ACGTU", "ACGTéñßЖıǆ", "AC")
-_EOLS = ("\n", "\n", "\n", "\r\n", "\r", "\n\n", "\r\n\n", " \n", "\t\r\n", "\x0c\n", "\x1f\n")
-
-
-def wild_directory(seed):
-    """Directories further out than synth.mixed_directory: sites drawn from odd palettes (blanks and control white space INSIDE and
-    at the end of lines, `>` in sequences, digits and punctuation, U, characters whose upper case is longer than they are), line ends
-    mixed inside one file, lines before the first header, headers with leading blanks / commas / nothing at all, empty files,
-    files of blank lines, a header as the last line without a line end, one or two sequences, identical sequences, codons of N and
-    stops — and file names with blanks and commas.  (dict name -> bytes, flags)"""
-    import numpy as np
-    rng = np.random.default_rng([int(seed), 77])
-    flags = list(WILD_FLAGS[seed % len(WILD_FLAGS)])
-    files = {}
-    for i in range(int(rng.integers(3, 16))):
-        n = int(rng.choice([1, 2, 2, 3, 4, 5, 9, 20]))
-        L = int(rng.choice([0, 1, 2, 3, 4, 6, 9, 12, 30, 31, 63, 66, 128, 129, 300]))
-        pal = _PALETTES[int(rng.integers(0, len(_PALETTES)))]
-        odd = float(rng.choice([0.0, 0.0, 0.02, 0.2]))
-        base = [str(rng.choice(list("ACGT"))) for _ in range(L)]
-        seqs = []
-        for r in range(n):
-            x = list(base)
-            for j in rng.integers(0, max(L, 1), size=int(rng.integers(0, L // 10 + 2))).tolist():
-                if L:
-                    x[j] = str(rng.choice(list("ACGT")))
-            if odd and L:
-                for j in np.flatnonzero(rng.random(L) < odd).tolist():
-                    x[j] = str(rng.choice(list(pal)))
-            seqs.append("".join(x))
-        if rng.random() < 0.1 and n > 1:
-            seqs = [seqs[0]] * n
-        hk = int(rng.integers(0, 8))
-        heads = [(f"s{r}_pop{1 + r % 2}", f" s{r}", f"s{r},x={r}", f"s{r}\tdesc", "", f"s{r % 2}", f"s{r} pop1 ", f"ſ{r}é")[hk] for r in range(n)]
-        kind = int(rng.integers(0, 14))
-        eols = [str(rng.choice(list(_EOLS[:5]) if kind != 1 else list(_EOLS))) for _ in range(4 * n + 8)]
-        import itertools
-        e = itertools.cycle(eols)
-        wrap = int(rng.choice([0, 0, 0, 60, 7, 1]))
-        text = ""
-        if kind == 2:
-            text += "ACGT" + next(e) + "  stray line" + next(e)
-        for r, x in enumerate(seqs):
-            text += ">" + heads[r] + next(e)
-            if wrap and x:
-                for k in range(0, len(x), wrap):
-                    text += x[k:k + wrap] + next(e)
-            else:
-                text += x + next(e)
-            if kind == 3 and r == 0:
-                text += next(e) + "   " + next(e)
-        if kind == 4:
-            text = ""
-        elif kind == 5:
-            text = "\n\n\r\n \n"
-        elif kind == 6:
-            text += ">last header without a line end"
-        elif kind == 7:
-            text = text.rstrip("\r\n \t\x0c\x1f")
-        elif kind == 8 and n > 1 and L > 2:
-            text = text.replace(seqs[-1], seqs[-1][:-1], 1)
-        elif kind == 9:
-            text = " " + text
-        name = (f"w{i:02d}.fa", f"w{i:02d} x.fa", f"w{i:02d},y.fasta", f"w{i:02d}.é.fa")[int(rng.integers(0, 4))] if rng.random() < 0.3 else f"w{i:02d}.fa"
-        files[name] = text.encode("utf-8")
-    return files, flags
-
-
-GENERATORS = {"mixed": synth.mixed_directory, "wild": wild_directory}
+GENERATORS = {"mixed": synth.mixed_directory, "wild": synth.wild_directory, "big": synth.big_directory}
 
 
 def _call(fn, *a):
@@ -436,6 +367,6 @@ def check(path):
 
 if __name__ == "__main__":
     if sys.argv[1] == "make":
-        make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], extras="extras" in sys.argv[5:], gen="wild" if "wild" in sys.argv[5:] else "mixed")
+        make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], extras="extras" in sys.argv[5:], gen="wild" if "wild" in sys.argv[5:] else "big" if "big" in sys.argv[5:] else "mixed")
     else:
         sys.exit(check(sys.argv[2]))
