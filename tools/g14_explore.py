@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Hunt for differences from the reference beyond the frozen G14 seeds.
   make FIRST COUNT OUT.json [extras] [wild]   (build container; `wild`: wild_directory below instead of synth.mixed_directory; `extras`: also -f lists, --pipe, and populations at function level; runs /root/reference/PolyFastA.py on synth.mixed_directory(seed) for COUNT seeds)
-  check IN.json               (GPU box: python -m polyfasta_amd on the same directories, both ingest modes, every line)
+  check IN.json [--ranks N]   (GPU box; --ranks: every -d run as N rank processes on the one GPU; python -m polyfasta_amd on the same directories, both ingest modes, every line)
 The JSON is scratch (not a fixture); a seed that shows a difference belongs into tests/golden/gen_golden.py's G14_SEEDS."""
 import contextlib
 import io
@@ -201,6 +201,59 @@ def make(first, count, out, extras=False, gen="mixed"):
     json.dump({"generator": gen, "cases": cases}, open(out, "w"))
 
 
+def check_ranks(path, ranks):
+    """every -d run of the JSON as `ranks` processes on this one GPU (the real command line per rank, gloo between them in place of
+    RCCL, which refuses two ranks on one device: tests/_cli_rank_worker.py): rank 0's stdout, the exit codes, the last line of
+    rank 0's stderr where the reference dies"""
+    from polyfasta_amd import dist
+    from tests import _cases as C
+    blob = json.load(open(path))
+    cases = blob["cases"]
+    bad = rows = launches = 0
+    for case in cases:
+        files, flags = GENERATORS[case.get("generator", blob.get("generator", "mixed"))](case["seed"])
+        cds, jc = "--cds" in flags, "--jc" in flags
+        top = tempfile.mkdtemp()
+        d = write_dir(top, files)
+        for run in case["runs"]:
+            for name in run["removed"]:
+                if os.path.exists(os.path.join(d, name)):
+                    os.unlink(os.path.join(d, name))
+            out = os.path.join(top, "rank0.txt")
+            port = dist._free_port()
+            procs = []
+            for r in range(ranks):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONUTF8="1")
+                procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_cli_rank_worker.py"), out, "-d", d, "-s"] + flags, cwd=ROOT,
+                                              stderr=subprocess.PIPE, env=env))
+            errs = [p.communicate(timeout=600)[1].decode() for p in procs]
+            launches += 1
+            rcs = [p.returncode for p in procs]
+            want_rc = run["returncode"]
+            diff = None
+            if rcs != [want_rc] * ranks:
+                diff = f"exit codes {rcs} != {want_rc}: {errs[0][-300:]!r}"
+            elif want_rc and errs[0].strip().splitlines()[-1].replace("[rank0]: ", "") != run["stderr_tail"]:
+                diff = f"stderr {errs[0].strip().splitlines()[-1]!r} != {run['stderr_tail']!r}"
+            else:
+                gl = [norm(x, files) for x in open(out).read().split("\n")]
+                wl = [norm(x, files) for x in run["stdout"].replace("{TMP}", top).split("\n")]
+                if len(gl) != len(wl):
+                    diff = f"{len(gl)} lines != {len(wl)}"
+                else:
+                    for a, b in zip(gl, wl):
+                        if a != b and (b.startswith("#") or "," not in b or C.row_matches(a, b, cds, jc) is not None):
+                            diff = f"{a!r} != {b!r}"
+                            break
+                        rows += bool(b) and not b.startswith("#")
+            if diff:
+                bad += 1
+                print(f"DIFFERENCE {case.get('generator', '')} seed {case['seed']} as {ranks} ranks, removed {run['removed']}: {diff}", flush=True)
+        shutil.rmtree(top)
+    print(f"g14_explore: {launches} runs of {len(cases)} directories as {ranks} ranks on one GPU, {rows} rows compared, {bad} differences")
+    return 1 if bad else 0
+
+
 def check(path):
     from tests import _cases as C
     from tests.test_cli_odd_gpu import MODES, run_proc
@@ -368,5 +421,7 @@ def check(path):
 if __name__ == "__main__":
     if sys.argv[1] == "make":
         make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], extras="extras" in sys.argv[5:], gen="wild" if "wild" in sys.argv[5:] else "big" if "big" in sys.argv[5:] else "mixed")
+    elif len(sys.argv) > 4 and sys.argv[3] == "--ranks":
+        sys.exit(check_ranks(sys.argv[2], int(sys.argv[4])))
     else:
         sys.exit(check(sys.argv[2]))
