@@ -540,11 +540,11 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
                 specials.append((fidx, 0, "stdout", f"# file {path} is not FASTA!"))                        # :247 (always stdout)
             elif st[k] == PFA_FILE_UNEQUAL:
                 specials.append((fidx, 0, "comment", f"# Sequences do not have the same length: {name}"))   # :135-140
-            elif bad[k] or (b.key_rows is not None and not b.key_rows[k].any()):
-                # bytes that are not ASCII: this file is read as text, the way the reference reads it.  So is a file in which NO
-                # population key was found: none of its rows went to the card, and it is the card's repack that tells exact row
-                # lengths (blanks at line ends) and non-ASCII characters — what such a file prints (its length modulo 3, whether
-                # its sequences are equally long in CHARACTERS) is then the text reader's call (found by tools/g14_explore.py)
+            elif bad[k] or (b.key_rows is not None and not b.key_rows[k].any() and not _file_is_ascii(path)):
+                # bytes that are not ASCII: this file is read as text, the way the reference reads it.  It is the card's repack that
+                # tells them; of a file in which NO population key was found no row went to the card, so the host looks itself (one
+                # pass over its bytes) — what such a file prints (its length modulo 3, whether its sequences are equally long in
+                # CHARACTERS) is the text reader's call (found by tools/g14_explore.py: three characters in four bytes)
                 got = None
                 try:
                     with open(path, "r") as fh:                                                              # :239
@@ -596,6 +596,19 @@ def block_from_batch(b, res, syn, sfs_flat, args, paths, keys):
         if args.sfs:
             sfs = (sfs or []) + [u[6] for u in extra]
     return RowBlock(meta, res, syn, sfs, specials, io_error, ssx=ssx)
+
+
+def _file_is_ascii(path):
+    try:
+        with open(path, "rb") as fh:
+            while True:
+                chunk = fh.read(1 << 22)
+                if not chunk:
+                    return True
+                if not chunk.isascii():
+                    return False
+    except OSError:
+        return True      # (cannot be read: the caller's other branches deal with it)
 
 
 def raise_unreadable(path):

@@ -139,10 +139,14 @@ def syn_tie_candidates(syn_num, n_sites, missing_cols=None):
     look = syn[:, 8:].any(axis=1) | (cols * np.spacing(np.maximum(n_sites, 1.0)) > 1e-8)
     out = np.zeros(len(syn), dtype=bool)
     if missing_cols is not None and len(syn):
-        k3_all = 3.0 * np.arange(1, 65, dtype=np.float64)
-        x_all = (syn[:, 1:].astype(np.float64) / k3_all).sum(axis=1)
-        left = (n_sites - 3.0 * np.asarray(missing_cols, dtype=np.float64)) - x_all
-        out |= (np.abs(left) < 1e-6) & (x_all > 0)
+        # a clean codon column is worth at most 4/3 synonymous sites of its 3: the counts can only meet when ONE clean column
+        # stands against one or two counted sites (a partial last codon: seqlen - 3 x missing <= 2) — nothing to look at in an
+        # ordinary batch
+        counted = n_sites - 3.0 * np.asarray(missing_cols, dtype=np.float64)
+        few = np.flatnonzero(counted <= 2.0)
+        if len(few):
+            x_few = (syn[few, 1:].astype(np.float64) / (3.0 * np.arange(1, 65, dtype=np.float64))).sum(axis=1)
+            out[few] = (np.abs(counted[few] - x_few) < 1e-6) & (x_few > 0)
     if not look.any():
         return out
     idx = np.flatnonzero(look)
@@ -226,6 +230,8 @@ def _term_pool(vals):
             perms = rng.permuted(np.tile(np.array(vals, dtype=np.float64), (4096, 1)), axis=1)
         sums = np.add.accumulate(perms, axis=1)[:, -1] / k          # left to right, like sum() from 0
         pool = None if (sums == sums[0]).all() else sums
+        if len(_TERM_POOLS) > 4096:      # (five values, up to 64 of them: a bounded but large family; the common ones come back at once)
+            _TERM_POOLS.clear()
         _TERM_POOLS[vals] = pool
     return pool
 

@@ -268,10 +268,10 @@ def test_carriage_returns_on_standard_input_and_in_files(gpu, g13, tmp_path, mon
 
 @pytest.mark.parametrize("mode", list(MODES))
 def test_files_in_which_no_population_key_is_found(gpu, g13, tmp_path, monkeypatch, mode):
-    """None of such a file's rows goes to the card, and it is the card's repack that tells exact row lengths and non-ASCII
-    characters: a length of 3 characters that is 4 bytes (no "not a multiple of 3" line), sequences equally long in bytes but not
-    in characters (unequal lengths), blanks and control white space at line ends that are no sites — the comment lines of the
-    reference's main() on its own reading of the files; and a file in which one key of two is found."""
+    """None of such a file's rows goes to the card, and it is the card's repack that tells non-ASCII characters: a length of 3
+    characters that is 4 bytes (no "not a multiple of 3" line), sequences equally long in bytes but not in characters (unequal
+    lengths) — the host looks at the bytes of such a file itself; blanks and control white space at line ends that are no sites
+    (the loader's own count); and a file in which one key of two is found: the comment lines of the reference's main()."""
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
     nk = g13["no_key_found"]
