@@ -223,7 +223,9 @@ def getvarCDSsites(d, seqlen):
     Position lists are ascending (the reference's within-codon order differs;
     only float summation order could depend on it).  The count is the reference's own
     column-by-column floating-point accumulation (PolyFastA.py:307), replayed on the host
-    from the codon sets the card returns per column (stats.syn_sites_replay)."""
+    from the codon sets the card returns per column (stats.syn_sites_replay) — on a two-decimal rounding tie whose
+    digit the reference itself does not fix (the summation order of a column of three or more codons follows its hash
+    seed) the value it most often has (stats.syn_sites_most_likely, tests/golden G15)."""
     m = fasta.matrix_from_dict(d, seqlen)
     if m.shape[0] == 0 or seqlen == 0:
         return 0.0, [], [], 0, 0
