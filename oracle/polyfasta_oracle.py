@@ -311,7 +311,7 @@ def getvarCDSsites(d, seqlen):
     return count_syn, syn, non, nstops, missing
 
 
-def count_syn_outcomes(d, seqlen, trials=200, seed=0):
+def count_syn_outcomes(d, seqlen, trials=200, seed=0, zero_flag=False):
     """What the reference PRINTS for sites_S / sites_N over its own run-to-run freedom: ref:292 makes each codon column a
     list(set(...)) of strings and ref:307 sums syncodfreq over it with sum([...]) — in the set's iteration order, which
     Python's randomised string hashing draws anew in every run.  Restated with the order drawn explicitly (a shuffle per
@@ -335,7 +335,10 @@ def count_syn_outcomes(d, seqlen, trials=200, seed=0):
             if len(vals) > 2:
                 rnd.shuffle(vals)
             count_syn += sum(vals) / len(vals)
-        out[(round(count_syn, 2), round((seqlen - missing) - count_syn, 2))] += 1
+        nsites = (seqlen - missing) - count_syn
+        # zero_flag: a non-synonymous site count of exactly 0.0 as an outcome of its own (the reference then dies with
+        # ZeroDivisionError where it otherwise divides by the noise of its accumulation)
+        out[(round(count_syn, 2), round(nsites, 2)) + ((nsites == 0,) if zero_flag else ())] += 1
     return out
 
 

@@ -296,6 +296,24 @@ def check(path):
                     tail = p.stderr.decode().strip().splitlines()[-1] if p.stderr.strip() else ""
                 gl, wl = [norm(x, files) for x in out.split("\n")], [norm(x, files) for x in want.split("\n")]
                 diff = None
+                if rc != run["returncode"] and cds and "ZeroDivisionError" in ((tail or "") + (run.get("stderr_tail") or "")) and {rc, run["returncode"]} == {0, 1}:
+                    # one of the two died dividing by a non-synonymous site count of exactly zero, the other divided by the noise of
+                    # its accumulation: the reference's own outcome follows its hash seed there (G15 zero_nonsynonymous_sites)
+                    died_first = sorted(files)[len([x for x in (out if rc else run["stdout"]).split("\n") if x and not x.startswith("#")]):]
+                    zs = []
+                    for n in sorted(files):
+                        try:
+                            dd = orc.readfasta(os.path.join(d, n))
+                        except Exception:      # noqa: BLE001
+                            continue
+                        if dd and len({len(x) for x in dd.values()}) == 1:
+                            o = orc.count_syn_outcomes(dd, len(next(iter(dd.values()))), trials=300, seed=2, zero_flag=True)
+                            if len({k[2] for k in o}) == 2:
+                                zs.append((n, dict(o)))
+                    if zs:
+                        unfixed.append((case["seed"], zs[0][0], "exit %d" % rc, "exit %d" % run["returncode"], zs[0][1],
+                                        (max(zs[0][1], key=zs[0][1].get)[2]) == (rc == 1)))
+                        continue
                 if rc != run["returncode"]:
                     diff = f"exit code {rc} != {run['returncode']}"
                 elif tail is not None and tail != run["stderr_tail"]:
@@ -346,7 +364,9 @@ def check(path):
 
                 fr = case["files_run"]
                 argv = ["-f"] + [os.path.join(d, n) for n in reversed(names)] + ["-s"] + flags
-                if fr["returncode"] == 0:
+                if any(u[0] == case["seed"] and str(u[2]).startswith("exit") for u in unfixed):
+                    pass      # (a directory whose -d run already met the die-or-print coin of the reference: the same file again)
+                elif fr["returncode"] == 0:
                     rc, out = run_inproc(argv)
                     lines_differ(out, fr["stdout"].replace("{TMP}", top), "-f list") if rc == 0 else print(f"DIFFERENCE seed {case['seed']} -f list: exit code {rc}")
                     bad += rc != 0
