@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Hunt for differences from the reference beyond the frozen G14 seeds.
   make FIRST COUNT OUT.json [extras] [wild]   (build container; `wild`: wild_directory below instead of synth.mixed_directory; `extras`: also -f lists, --pipe, and populations at function level; runs /root/reference/PolyFastA.py on synth.mixed_directory(seed) for COUNT seeds)
-  check IN.json [--ranks N]   (GPU box; --ranks: every -d run as N rank processes on the one GPU; python -m polyfasta_amd on the same directories, both ingest modes, every line)
+  check IN.json [--ranks N [--pops] [--limit K]]   (GPU box; --ranks: every -d run (--pops: the -p lines) of the first K directories as N rank processes on the one GPU; python -m polyfasta_amd on the same directories, both ingest modes, every line)
 The JSON is scratch (not a fixture); a seed that shows a difference belongs into tests/golden/gen_golden.py's G14_SEEDS."""
 import contextlib
 import io
@@ -201,17 +201,25 @@ def make(first, count, out, extras=False, gen="mixed"):
     json.dump({"generator": gen, "cases": cases}, open(out, "w"))
 
 
-def check_ranks(path, ranks):
+def check_ranks(path, ranks, pops=False, limit=None):
     """every -d run of the JSON as `ranks` processes on this one GPU (the real command line per rank, gloo between them in place of
     RCCL, which refuses two ranks on one device: tests/_cli_rank_worker.py): rank 0's stdout, the exit codes, the last line of
     rank 0's stderr where the reference dies"""
     from polyfasta_amd import dist
     from tests import _cases as C
     blob = json.load(open(path))
-    cases = blob["cases"]
+    cases = blob["cases"][:limit]
     bad = rows = launches = 0
     for case in cases:
         files, flags = GENERATORS[case.get("generator", blob.get("generator", "mixed"))](case["seed"])
+        if pops:
+            # -p through the ranks: the lines of the reference's functions per key (made with `extras`), the whole directory but the
+            # files it cannot decode
+            pp = case["pops"]
+            if any(ln.startswith("!") for ln in pp["stdout"].split("\n")):
+                continue
+            case = dict(case, runs=[{"removed": pp["skipped"], "returncode": 0, "stdout": pp["stdout"]}])
+            flags = ["-p", ",".join(pp["keys"])] + flags
         cds, jc = "--cds" in flags, "--jc" in flags
         top = tempfile.mkdtemp()
         d = write_dir(top, files)
@@ -442,6 +450,6 @@ if __name__ == "__main__":
     if sys.argv[1] == "make":
         make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], extras="extras" in sys.argv[5:], gen="wild" if "wild" in sys.argv[5:] else "big" if "big" in sys.argv[5:] else "mixed")
     elif len(sys.argv) > 4 and sys.argv[3] == "--ranks":
-        sys.exit(check_ranks(sys.argv[2], int(sys.argv[4])))
+        sys.exit(check_ranks(sys.argv[2], int(sys.argv[4]), pops="--pops" in sys.argv[5:], limit=int(sys.argv[sys.argv.index("--limit") + 1]) if "--limit" in sys.argv else None))
     else:
         sys.exit(check(sys.argv[2]))
