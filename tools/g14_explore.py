@@ -17,7 +17,39 @@ sys.path.insert(0, ROOT)
 from polyfasta_amd import synth  # noqa: E402
 
 
-GENERATORS = {"mixed": synth.mixed_directory, "wild": synth.wild_directory, "big": synth.big_directory}
+def extreme_directory(seed):
+    """shapes at the edges: thousands of sequences of a few sites, two sequences of 100 000 sites, a header of 100 000 characters,
+    5 000 sequences of one site, a sequence wrapped one site per line, identical sequences, every sequence different at every site"""
+    import numpy as np
+    rng = np.random.default_rng([int(seed), 123])
+    flags = list(synth.WILD_FLAGS[seed % 4])
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def aln(n, L, rate, heads=None, wrap=0):
+        base = rng.choice(acgt, size=L)
+        m = np.repeat(base[None, :], n, axis=0)
+        hit = rng.random((n, L)) < rate
+        m[hit] = rng.choice(acgt, size=int(hit.sum()))
+        out = []
+        for r in range(n):
+            x = m[r].tobytes().decode()
+            body = "\n".join(x[k:k + wrap] for k in range(0, L, wrap)) if wrap else x
+            out.append(f">{heads[r] if heads else 's%d_pop%d' % (r, 1 + r % 2)}\n{body}\n")
+        return "".join(out).encode()
+
+    files = {
+        "e0_many_short.fa": aln(int(rng.choice([2049, 3000, 5000])), int(rng.choice([3, 4, 6])), 0.05),
+        "e1_two_long.fa": aln(2, int(rng.choice([65536, 100000, 100001])), 0.001),
+        "e2_long_header.fa": aln(3, 33, 0.1, heads=["h" * 100000, "i" * 70000 + " pop1", "j"]),
+        "e3_one_site.fa": aln(5000, 1, 0.3),
+        "e4_site_per_line.fa": aln(4, 999, 0.02, wrap=1),
+        "e5_identical.fa": aln(int(rng.choice([7, 64, 65, 213, 214])), 600, 0.0),
+        "e6_all_different.fa": aln(int(rng.choice([4, 40, 300])), int(rng.choice([30, 300])), 0.75),
+    }
+    return files, flags
+
+
+GENERATORS = {"mixed": synth.mixed_directory, "wild": synth.wild_directory, "big": synth.big_directory, "extreme": extreme_directory}
 
 
 def _call(fn, *a):
@@ -448,7 +480,7 @@ def check(path):
 
 if __name__ == "__main__":
     if sys.argv[1] == "make":
-        make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], extras="extras" in sys.argv[5:], gen="wild" if "wild" in sys.argv[5:] else "big" if "big" in sys.argv[5:] else "mixed")
+        make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], extras="extras" in sys.argv[5:], gen=next((g for g in ("wild", "big", "extreme") if g in sys.argv[5:]), "mixed"))
     elif len(sys.argv) > 4 and sys.argv[3] == "--ranks":
         sys.exit(check_ranks(sys.argv[2], int(sys.argv[4]), pops="--pops" in sys.argv[5:], limit=int(sys.argv[sys.argv.index("--limit") + 1]) if "--limit" in sys.argv else None))
     else:
