@@ -12,7 +12,7 @@ _lib.init(0)
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first_seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 t0 = time.time()
-units_checked = 0
+units_checked = unfixed = 0
 for seed in range(first_seed, first_seed + n_seeds):
     rng = np.random.default_rng(seed)
     lean = seed % 2 == 0
@@ -59,9 +59,18 @@ for seed in range(first_seed, first_seed + n_seeds):
                        (o["seg_S"], o["seg_N"], o["H_S"], o["H_N"], o["nstops"], o["missing_cols"]), (seed, i, m.shape)
                 assert abs(stats.syn_sites_from_bins(out.syn_num[i]) - o["count_syn"]) <= 1e-9 * max(1.0, o["count_syn"])
                 if exact:
-                    assert float(out.sites_s[i]) == o["count_syn"], (seed, i, m.shape)      # the same double as the column-order sum
+                    if float(out.sites_s[i]) != o["count_syn"]:
+                        # only where the reference itself has more than one answer (a rounding tie or a non-synonymous site count of
+                        # zero, and a column whose term follows its summation order: tests/golden G15): there its commonest
+                        from tests import _cases as C
+                        sub = m if rows is None else m[rows]
+                        sets = C.codon_sets_numpy(sub)
+                        assert stats.syn_tie_candidates(C.syn_bins_numpy(sub)[None, :], [m.shape[1]], [int((sets == 0).sum())])[0], (seed, i, m.shape)
+                        assert float(out.sites_s[i]) == stats.syn_sites_most_likely(sets, m.shape[1]), (seed, i, m.shape)
+                        assert abs(float(out.sites_s[i]) - o["count_syn"]) < 1e-12
+                        unfixed += 1
         else:
             T._compare(out, i, o, cds)
         units_checked += 1
     print(f"seed {seed} ok ({'lean' if lean else 'general'}, tiles {tw or 'auto'}, {len(units)} units)", flush=True)
-print(f"soak: {units_checked} units over {n_seeds} seeds identical to the oracle in {time.time() - t0:.0f} s")
+print(f"soak: {units_checked} units over {n_seeds} seeds identical to the oracle in {time.time() - t0:.0f} s ({unfixed} replayed counts on a tie the reference itself does not fix: there its commonest value)")
