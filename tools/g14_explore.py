@@ -224,6 +224,33 @@ def make(first, count, out, extras=False, gen="mixed"):
                         except ZeroDivisionError:
                             print(f"!ZeroDivisionError {n} {pop}")
             case["pops"] = {"keys": keys, "skipped": skipped, "stdout": buf.getvalue().replace(top + "/", "{TMP}/")}
+            # --pipe -p: the same per-key lines for the reference's own reading of standard input (lines at \n only)
+            case["pipe_pops"] = []
+            for n in names[:4]:
+                keep, buf = sys.stdin, io.StringIO()
+                sys.stdin = io.TextIOWrapper(io.BytesIO(files[n]), encoding="utf-8", errors="surrogateescape", newline="\n")
+                try:
+                    with contextlib.redirect_stdout(buf):
+                        dd = ref.readfasta("stdin", True)
+                        if type(dd) == dict:
+                            lens = [len(x) for x in dd.values()]
+                            if any(x != lens[0] for x in lens):
+                                print("# Sequences do not have the same length: stdin")
+                            else:
+                                if cds and lens[0] % 3:
+                                    print("# CDS sequence length is not a multiple of 3: stdin")
+                                for pop in keys:
+                                    grp = [k for k in dd if pop in k]
+                                    if not grp:
+                                        print(f"# Pop {pop} string was not found in fasta headers.")
+                                        continue
+                                    try:
+                                        ref.print_result({k: dd[k] for k in grp}, lens[0], cds, "", "a", "stdin", pop, True, 0, jc)
+                                    except ZeroDivisionError:
+                                        print("!ZeroDivisionError")
+                finally:
+                    sys.stdin = keep
+                case["pipe_pops"].append({"file": n, "stdout": buf.getvalue()})
             # the statistics functions one by one (what polyfasta_amd/api.py mirrors), on every file the reference can read
             case["api"] = {n: api_record(ref, os.path.join(d, n)) for n in names if n not in skipped}
         shutil.rmtree(top)
@@ -462,6 +489,20 @@ def check(path):
                             bad += 1
                             print(f"DIFFERENCE seed {case['seed']} api {n} {k}: {got_rec.get(k)!r} != {want_rec.get(k)!r}", flush=True)
                         api_files += 1
+                for pr in case.get("pipe_pops", []) if mode == "direct" else []:
+                    if "!" in pr["stdout"]:
+                        continue
+                    keep = sys.stdin
+                    sys.stdin = io.TextIOWrapper(io.BytesIO(files[pr["file"]]), encoding="utf-8", errors="surrogateescape")
+                    try:
+                        rc, out = run_inproc(["--pipe", "-s", "-p", ",".join(case["pops"]["keys"])] + flags)
+                    finally:
+                        sys.stdin = keep
+                    if rc != 0:
+                        bad += 1
+                        print(f"DIFFERENCE seed {case['seed']} --pipe -p {pr['file']}: {rc} {out[-200:]!r}", flush=True)
+                    else:
+                        lines_differ(out, pr["stdout"], f"--pipe -p {pr['file']}")
                 pp = case["pops"]
                 if not any(ln.startswith("!") for ln in pp["stdout"].split("\n")):
                     for n in pp["skipped"]:
