@@ -2,6 +2,7 @@
 """Hunt for differences from the reference beyond the frozen G14 seeds.
   make FIRST COUNT OUT.json [extras] [wild]   (build container; `wild`: wild_directory below instead of synth.mixed_directory; `extras`: also -f lists, --pipe, and populations at function level; runs /root/reference/PolyFastA.py on synth.mixed_directory(seed) for COUNT seeds)
   check IN.json [--ranks N [--pops] [--limit K]]   (GPU box; --ranks: every -d run (--pops: the -p lines) of the first K directories as N rank processes on the one GPU; python -m polyfasta_amd on the same directories, both ingest modes, every line)
+  oracle IN.json              (no GPU: both oracles against the -d transcripts)
 The JSON is scratch (not a fixture); a seed that shows a difference belongs into tests/golden/gen_golden.py's G14_SEEDS."""
 import contextlib
 import io
@@ -258,6 +259,69 @@ def make(first, count, out, extras=False, gen="mixed"):
         if seed % 25 == 0:
             print(f"seed {seed}", flush=True)
     json.dump({"generator": gen, "cases": cases}, open(out, "w"))
+
+
+def check_oracle(path):
+    """no GPU: the Python oracle (its reader, its rows) and the C oracle (the scan of the same alignment as a byte matrix, finished
+    by the integer-summary formatter) against the -d transcripts of the JSON — the checkers themselves against the reference"""
+    from oracle import c_oracle
+    from oracle import polyfasta_oracle as orc
+    from polyfasta_amd import fasta
+    from tests import _cases as C
+    blob = json.load(open(path))
+    bad = rows = coins = 0
+    for case in blob["cases"]:
+        files, flags = GENERATORS[case.get("generator", blob.get("generator", "mixed"))](case["seed"])
+        cds, jc = "--cds" in flags, "--jc" in flags
+        top = tempfile.mkdtemp()
+        d = write_dir(top, files)
+        run = case["runs"][-1]
+        if run["returncode"] == 0:
+            want = [norm(ln, files) for ln in run["stdout"].replace("{TMP}", top).split("\n") if ln]
+            got = []
+            for name in sorted(files):
+                if name in run["removed"]:
+                    continue
+                try:
+                    dd = orc.readfasta(os.path.join(d, name))
+                except Exception as e:      # noqa: BLE001
+                    got.append(f"!{type(e).__name__} {name}")
+                    continue
+                if dd is None:
+                    got.append(f"# file {os.path.join(d, name)} is not FASTA!")
+                    continue
+                lens = {len(x) for x in dd.values()}
+                if len(lens) != 1:
+                    got.append(f"# Sequences do not have the same length: {name}")
+                    continue
+                L = lens.pop()
+                if cds and L % 3:
+                    got.append(f"# CDS sequence length is not a multiple of 3: {name}")
+                try:
+                    row = orc.result_row(dd, L, cds, name, "NA", jc)
+                    m = fasta.matrix_from_dict(dd)
+                    crow = orc.row_from_counts(name, "NA", len(dd), L, c_oracle.scan(m, cds=cds), cds, jc) if m.shape[1] else row
+                except ZeroDivisionError:
+                    row = crow = f"!ZeroDivisionError {name}"
+                got.append(norm(row, files) + "\t" + norm(crow, files))
+            if len(got) != len(want):
+                bad += 1
+                print(f"DIFFERENCE seed {case['seed']}: {len(got)} lines != {len(want)}", flush=True)
+            else:
+                for g, b in zip(got, want):
+                    for a in g.split("\t"):
+                        if a == b:
+                            continue
+                        if cds and not b.startswith("#") and a.split(",")[1:3] != b.split(",")[1:3] and a.split(",")[0] == b.split(",")[0]:
+                            coins += 1      # (a digit the reference itself does not fix: the checkers sum in one order, G15)
+                            a = ",".join(a.split(",")[:1] + b.split(",")[1:3] + a.split(",")[3:])
+                        if b.startswith("#") or a.startswith("!") or C.row_matches(a, b, cds, jc) is not None:
+                            bad += 1
+                            print(f"DIFFERENCE seed {case['seed']}: {a!r} != {b!r}", flush=True)
+                    rows += not b.startswith("#")
+        shutil.rmtree(top)
+    print(f"g14_explore: both oracles against the reference on {len(blob['cases'])} directories: {rows} rows, {bad} differences ({coins} digits the reference itself does not fix)")
+    return 1 if bad else 0
 
 
 def check_ranks(path, ranks, pops=False, limit=None):
@@ -522,6 +586,8 @@ def check(path):
 if __name__ == "__main__":
     if sys.argv[1] == "make":
         make(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], extras="extras" in sys.argv[5:], gen=next((g for g in ("wild", "big", "extreme") if g in sys.argv[5:]), "mixed"))
+    elif sys.argv[1] == "oracle":
+        sys.exit(check_oracle(sys.argv[2]))
     elif len(sys.argv) > 4 and sys.argv[3] == "--ranks":
         sys.exit(check_ranks(sys.argv[2], int(sys.argv[4]), pops="--pops" in sys.argv[5:], limit=int(sys.argv[sys.argv.index("--limit") + 1]) if "--limit" in sys.argv else None))
     else:
