@@ -244,3 +244,28 @@ def test_zero_nonsynonymous_sites_g15(gpu, tmp_path):
     assert p.returncode == most["returncode"] == 1
     assert p.stdout.decode() == most["stdout"]
     assert p.stderr.decode().strip().splitlines()[-1] == most["stderr_tail"]
+
+
+def test_jukes_cantor_at_its_singularity_g15(gpu, tmp_path):
+    """G15 `jc_singularity`, a KNOWN DEVIATION: pi per site of exactly 0.75 makes the correction -0.75 log(1 - 4/3 x) undefined.
+    The reference evaluates pi in floating point; where its rounding noise leaves 0.7499999999999999 it prints -0.75 log(2.2e-16)
+    = 27.03, where it leaves 0.75 its bare `except` prints the uncorrected 0.75 (PolyFastA.py:512-516) — for the second text
+    either, by hash seed.  This implementation computes pi from exact integers and always prints the reference's fallback, 0.75:
+    one of the reference's own outputs for the second text, not for the first.  Every other column is the reference's."""
+    g = C.load("g15_hash_seed_ties.json")["jc_singularity"]
+    for case in g:
+        f = tmp_path / "x.fa"
+        f.write_bytes(case["text"].encode())
+        rc, out = run_cli(["-f", str(f), "-s"] + case["flags"])
+        assert rc == 0
+        got = out.rstrip("\n").split("\n")[-1].split(",")
+        cds = "--cds" in case["flags"]
+        col = 8 if cds else 5          # pi_N / pi
+        refs = [r.split(",") for r, _ in case["rows"]]
+        assert float(got[col]) == 0.75
+        assert all(float(r[col]) == 0.75 or float(r[col]) > 20.0 for r in refs)
+        for r in refs:
+            same = got[:col] + [r[col]] + got[col + 1:]
+            assert C.row_matches(",".join(same), ",".join(r), cds, True) is None, (case["label"], got, r)
+        if case["label"] == "five_sequences_two_sites":
+            assert any(float(r[col]) == 0.75 for r in refs)          # here the product prints one of the reference's own rows

@@ -115,6 +115,25 @@ def api_differs(a, b):
     return None
 
 
+def jc_singular(a, b, cds):
+    """two rows that differ only in a Jukes-Cantor corrected pi at the correction's singularity (pi per site = 0.75: one side
+    prints the uncorrected 0.75 of the reference's `except`, the other -0.75 log of rounding noise, 26.7 or 27.0): tests/golden
+    G15 `jc_singularity`, a known deviation.  Returns b with those columns taken from a, or None."""
+    fa, fb = a.rsplit(",", 13 if cds else 7), b.rsplit(",", 13 if cds else 7)
+    if len(fa) != len(fb):
+        return None
+    hit = False
+    for col in ((7, 8) if cds else (5,)):
+        try:
+            x, y = float(fa[col]), float(fb[col])
+        except ValueError:
+            continue
+        if x != y and {min(x, y) == 0.75 or abs(min(x, y) - 0.75) < 1e-12, max(x, y) > 20.0} == {True}:
+            fb[col] = fa[col]
+            hit = True
+    return ",".join(fb) if hit else None
+
+
 def norm(line, files):
     """a row whose file name holds commas, with the commas of the name taken out (the rows are compared column by column)"""
     for name in files:
@@ -373,6 +392,9 @@ def check_ranks(path, ranks, pops=False, limit=None):
                     diff = f"{len(gl)} lines != {len(wl)}"
                 else:
                     for a, b in zip(gl, wl):
+                        if a != b and jc and not b.startswith("#") and jc_singular(a, b, cds):
+                            b = jc_singular(a, b, cds)
+                            singular.add((case["seed"], a.split(",")[0]))
                         if a != b and (b.startswith("#") or "," not in b or C.row_matches(a, b, cds, jc) is not None):
                             diff = f"{a!r} != {b!r}"
                             break
@@ -400,6 +422,7 @@ def check(path):
     cases, generate = blob["cases"], GENERATORS[blob.get("generator", "mixed")]
     bad = rows = api_files = 0
     unfixed = []
+    singular = set()
     for mode, env in MODES.items():
         for k in ("PFA_INGEST_NO_DIRECT", "PFA_INGEST_SLOT_BYTES"):
             os.environ.pop(k, None)
@@ -463,6 +486,9 @@ def check(path):
                             if pa in outs and pb in outs:
                                 unfixed.append((case["seed"], a.split(",")[0], pa, pb, dict(outs), max(outs, key=outs.get) == pa))
                                 b = ",".join(b.split(",")[:1] + a.split(",")[1:3] + b.split(",")[3:])
+                        if a != b and jc and not b.startswith("#") and jc_singular(a, b, cds):
+                            b = jc_singular(a, b, cds)
+                            singular.add((case["seed"], a.split(",")[0]))
                         if a != b and (b.startswith("#") or "," not in b or C.row_matches(a, b, cds, jc) is not None):
                             diff = f"{a!r} != {b!r}"
                             break
@@ -487,6 +513,9 @@ def check(path):
                     for a, b in zip(gl, wl):
                         if a != b and cds and not b.startswith(("#", "!")) and a.split(",")[0] == b.split(",")[0] and a.split(",")[1:3] != b.split(",")[1:3]:
                             b = ",".join(b.split(",")[:1] + a.split(",")[1:3] + b.split(",")[3:])      # (ties: judged in the -d run above)
+                        if a != b and jc and not b.startswith(("#", "!")) and jc_singular(a, b, cds):
+                            b = jc_singular(a, b, cds)
+                            singular.add((case["seed"], a.split(",")[0]))
                         if a != b and (b.startswith(("#", "!")) or "," not in b or C.row_matches(a, b, cds, jc) is not None):
                             bad += 1
                             print(f"DIFFERENCE seed {case['seed']} mode {mode} {what}: {a!r} != {b!r}", flush=True)
@@ -549,6 +578,10 @@ def check(path):
                     for n, want_rec in case["api"].items():
                         got_rec = json.loads(json.dumps(api_record(product_api, os.path.join(d, n))))
                         k = api_differs(got_rec, want_rec)
+                        if k == "polymorphism_jc1" and isinstance(got_rec.get(k), list) and isinstance(want_rec.get(k), list) and \
+                                {min(got_rec[k][1], want_rec[k][1]) == 0.75, max(got_rec[k][1], want_rec[k][1]) > 20.0} == {True}:
+                            singular.add((case["seed"], n))      # (the Jukes-Cantor singularity, as above)
+                            k = None
                         if k is not None:
                             bad += 1
                             print(f"DIFFERENCE seed {case['seed']} api {n} {k}: {got_rec.get(k)!r} != {want_rec.get(k)!r}", flush=True)
@@ -579,7 +612,7 @@ def check(path):
     for u in unfixed:
         print(f"tie the reference does not fix: seed {u[0]} {u[1]}: printed {u[2]}, the reference under PYTHONHASHSEED=0 {u[3]}; the checker's outcomes {u[4]}; printed the commonest: {u[5]}")
     bad += sum(1 for u in unfixed if not u[5])
-    print(f"g14_explore: {len(cases)} directories in {len(MODES)} ingest modes, {rows} rows compared, {bad} differences, {len(unfixed)} rows (both modes counted) on a tie the reference itself does not fix; {api_files} files through the statistics functions one by one")
+    print(f"g14_explore: {len(cases)} directories in {len(MODES)} ingest modes, {rows} rows compared, {bad} differences, {len(unfixed)} rows (both modes counted) on a tie the reference itself does not fix; {api_files} files through the statistics functions one by one; {len(singular)} files at the Jukes-Cantor singularity (pi per site 0.75: a known deviation, tests/golden G15)")
     return 1 if bad else 0
 
 
