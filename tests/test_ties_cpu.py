@@ -221,3 +221,20 @@ def test_zero_nonsynonymous_sites_die_or_print_like_the_reference_mostly_does_g1
     for a in range(20):
         mm = synth.synth_alignment(7, a, 300, p, coding=True)
         assert not stats.syn_tie_candidates(C.syn_bins_numpy(mm)[None, :], [300], [int((C.codon_sets_numpy(mm) == 0).sum())])[0]
+
+
+def test_jukes_cantor_singularity_the_oracle_has_the_references_noise_g15():
+    """G15 `jc_singularity`: at pi per site = 0.75 the reference prints -0.75 log of its own rounding noise (27.03 / 26.73) or, when
+    the noise is nil, the uncorrected 0.75 of its bare `except`.  The Python oracle restates the reference's floating-point evaluation
+    of pi (PolyFastA.py:485-492) and lands on one of the rows the reference printed — the very row where the reference has only
+    one.  (The product, which finishes pi from exact integers, always prints the fallback: DESIGN.md §8, tests/test_ties_gpu.py.)"""
+    import io
+    from oracle import polyfasta_oracle as orc
+    for case in C.load("g15_hash_seed_ties.json")["jc_singularity"]:
+        d = orc.parse_fasta_lines(io.StringIO(case["text"], newline=None))
+        L = len(next(iter(d.values())))
+        cds = "--cds" in case["flags"]
+        row = orc.result_row(d, L, cds, "x.fa", "NA", True)
+        assert any(C.row_matches(row, r, cds, True) is None for r, _ in case["rows"]), (case["label"], row, case["rows"])
+        # and the exact-integer finish takes the fallback branch
+        assert stats.finish_polymorphism(3, 18, 3, 4, True)[1] == 0.75          # 18 / (3 x 2) / 4 = 0.75: log(0), the bare except
